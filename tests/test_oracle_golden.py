@@ -1,0 +1,164 @@
+"""Pins the CPU oracle (oracle/kx_oracle.c) against
+  (a) the known-answer vectors held by the reference's own tests, and
+  (b) fixtures generated from the reference's Python (tests/golden/make_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import kxo
+
+
+# ---- (a) reference known-answer tests ------------------------------------------------------
+def test_ref_matmul_linear_course():
+    # test/test_op/test_cu_matmul.cpp:48-76 : W = 1..9 (3x3), x = [1,1,-1] -> [0,3,6]
+    w = np.arange(1, 10, dtype=np.float32).reshape(3, 3)
+    y = kxo.gemv_f32(np.array([1, 1, -1], np.float32), w)
+    assert y.tolist() == [0.0, 3.0, 6.0]
+
+
+def test_ref_matmul_linear_stream5():
+    # test/test_op/test_cu_matmul.cpp:10-46 : W = 0..15 (4x4), x = 0..3 (CUDA == CPU there)
+    w = np.arange(16, dtype=np.float32).reshape(4, 4)
+    x = np.arange(4, dtype=np.float32)
+    assert kxo.gemv_f32(x, w).tolist() == (w @ x).tolist()
+
+
+def test_ref_test_load_create_matmul():
+    # test/test_op/test_load.cpp:97-105 : w = arange(2048).reshape(16,128), x = ones
+    w = np.arange(2048, dtype=np.float32).reshape(16, 128)
+    y = kxo.gemv_f32(np.ones(128, np.float32), w)
+    assert y[0] == 8128 and y[1] == 24512 and y[14] == 237504 and y[15] == 253888
+
+
+# ---- (b) quantiser + W8 GEMV (G1/G2) ---------------------------------------------------------
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_quantize_q80_bit_exact(golden, name):
+    g = golden("g1_quant_gemv.npz")
+    q, s = kxo.quantize_q80(g[f"{name}_w"], 64)
+    assert np.array_equal(q, g[f"{name}_q"])
+    assert np.array_equal(s, g[f"{name}_s"])
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_gemv_w8_vs_golden(golden, name):
+    g = golden("g1_quant_gemv.npz")
+    x, q, s = g[f"{name}_x"], g[f"{name}_q"], g[f"{name}_s"]
+    y = kxo.gemv_w8(x, q, s, 64)
+    K, M = q.shape
+    absum = (np.abs(x.astype(np.float64))[None, :] * np.repeat(s.astype(np.float64), 64).reshape(
+        K, M) * np.abs(q.astype(np.float64))).sum(1)
+    # fp64 evaluation of the reference formula; the oracle rounds each product to fp32
+    assert np.all(np.abs(y - g[f"{name}_y64"]) <= 2e-7 * absum + 1e-30)
+    # dequantise-then-linear cross check (torch fp32 sum order): looser
+    assert np.all(np.abs(y - g[f"{name}_ylinear"]) <= 2e-6 * absum)
+    # threaded path gives the same bits
+    assert np.array_equal(y, kxo.gemv_w8(x, q, s, 64, threads=4))
+
+
+# ---- (b) attention (G5) ---------------------------------------------------------------------
+def _attn_cases(g):
+    n = int(g["n_cases"])
+    for i in range(n):
+        meta = g[f"c{i}_meta"]
+        cid = int(meta[8])
+        yield f"c{i}", meta, g[f"c{i}_q"], g[f"cache{cid}_k"], g[f"cache{cid}_v"], g[f"c{i}_out"]
+    yield "ref", g["ref_meta"], g["ref_q"], g["ref_kc"], g["ref_vc"], g["ref_out"]
+
+
+def test_attention_vs_golden(golden):
+    g = golden("g5_attention.npz")
+    for name, meta, q, kc, vc, want in _attn_cases(g):
+        H, KVH, hs, S, pos, Tq, L, layer = [int(v) for v in meta[:8]]
+        got = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, layer)
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-6, err_msg=name)
+        if Tq == 1:  # decode: the MHA kernel entry gives the same answer
+            out, score = kxo.mha(pos, H, layer, S, KVH * hs, H // KVH, hs, q.reshape(-1), kc, vc,
+                                 want_score=True)
+            np.testing.assert_allclose(out.reshape(1, H, hs), want, rtol=0, atol=3e-6)
+            np.testing.assert_allclose(score[:, :pos + 1].sum(1), 1.0, atol=1e-5)
+
+
+def test_prefill_rows_equal_sequential_decode(golden):
+    g = golden("g5_attention.npz")
+    meta, q = g["c5_meta"], g["c5_q"]
+    H, KVH, hs, S, pos, Tq, L, layer, cid = [int(v) for v in meta]
+    kc, vc = g[f"cache{cid}_k"], g[f"cache{cid}_v"]
+    full = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, layer)
+    for i in (0, 1, Tq // 2, Tq - 1):
+        row = kxo.mha(pos - (Tq - 1) + i, H, layer, S, KVH * hs, H // KVH, hs, q[i].reshape(-1),
+                      kc, vc)
+        assert np.array_equal(row.reshape(H, hs), full[i])
+
+
+# ---- (b) whole token graph (G3 fp32, G4 int8) ---------------------------------------------------
+def _tiny_cfg():
+    return kxo.Config(rope_variant=kxo.ROPE_INTERLEAVED, rope_theta=10000.0, rms_eps=1e-5)
+
+
+def _run_stream(model, tokens, n_greedy):
+    logits = []
+    for pos, t in enumerate(tokens):
+        logits.append(model.forward(int(t), pos))
+    greedy = []
+    pos = len(tokens)
+    nxt = kxo.argmax(logits[-1])
+    for _ in range(n_greedy):
+        greedy.append(nxt)
+        lg = model.forward(nxt, pos)
+        pos += 1
+        nxt = kxo.argmax(lg)
+    return np.stack(logits), np.array(greedy, np.int32)
+
+
+def test_tiny_fp32_model_vs_reference_python(golden, golden_bytes):
+    g = golden("g3_tiny_fp32.npz")
+    m = kxo.Model(_tiny_cfg(), blob=golden_bytes("g3_tiny_fp32.bin"), quant=False)
+    c = m.cfg
+    assert (c.dim, c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size,
+            c.seq_len) == (128, 256, 2, 4, 2, 128, 32)
+    logits, greedy = _run_stream(m, g["tokens"], 16)
+    # sequential decode through the KV cache == the reference's full-sequence forward
+    scale = np.abs(g["logits"]).max()
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * scale
+    assert greedy.tolist() == g["greedy"].tolist()
+
+
+def test_tiny_q8_model_vs_reference_python(golden, golden_bytes):
+    g = golden("g4_tiny_q8.npz")
+    m = kxo.Model(_tiny_cfg(), blob=golden_bytes("g4_tiny_q8.bin"), quant=True)
+    assert m.cfg.group_size == 64
+    logits, greedy = _run_stream(m, g["tokens"], 16)
+    scale = np.abs(g["logits"]).max()
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * scale
+    assert greedy.tolist() == g["greedy"].tolist()
+
+
+# ---- support kernels: properties the reference's (disabled) tests state -----------------------
+def test_rope_variants_preserve_norm_and_pos0_identity():
+    rng = np.random.default_rng(0)
+    dim, kvd, hs = 256, 128, 64
+    for variant, theta in ((kxo.ROPE_INTERLEAVED, 1e4), (kxo.ROPE_HALF_SPLIT, 5e5),
+                           (kxo.ROPE_HALF_SPLIT, 1e6)):
+        s, c = kxo.sin_cos_cache(hs, 16, theta)
+        q = rng.standard_normal(dim).astype(np.float32)
+        k = rng.standard_normal(kvd).astype(np.float32)
+        q0, k0 = kxo.rope(variant, dim, kvd, hs, q, k, 0, s, c)
+        assert np.array_equal(q0, q) and np.array_equal(k0, k)
+        q5, k5 = kxo.rope(variant, dim, kvd, hs, q, k, 5, s, c)
+        np.testing.assert_allclose(np.linalg.norm(q5.reshape(-1, hs), axis=1),
+                                   np.linalg.norm(q.reshape(-1, hs), axis=1), rtol=1e-5)
+        np.testing.assert_allclose(np.linalg.norm(k5), np.linalg.norm(k), rtol=1e-5)
+
+
+def test_rmsnorm_swiglu_add_argmax():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(512).astype(np.float32)
+    w = rng.standard_normal(512).astype(np.float32)
+    want = w * (x / np.sqrt((x.astype(np.float64) ** 2).mean() + 1e-5))
+    np.testing.assert_allclose(kxo.rmsnorm(x, w, 1e-5), want, rtol=1e-5, atol=1e-6)
+    a = rng.standard_normal(300).astype(np.float32)
+    b = rng.standard_normal(300).astype(np.float32)
+    np.testing.assert_allclose(kxo.swiglu(a, b), a / (1 + np.exp(-a.astype(np.float64))) * b,
+                               rtol=1e-5, atol=1e-6)
+    assert np.array_equal(kxo.add(a, b), a + b)
+    assert kxo.argmax(np.array([1, 5, 5, 2], np.float32)) == 1  # first maximum wins
