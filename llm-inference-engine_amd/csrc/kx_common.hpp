@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kx_hip.h"
+
+#define KX_HIP_TRY(expr)                        \
+  do {                                          \
+    hipError_t e_ = (expr);                     \
+    if (e_ != hipSuccess) return (int)e_;       \
+  } while (0)
+
+// A kernel launch reports configuration errors through hipGetLastError.
+#define KX_LAUNCH_CHECK()                       \
+  do {                                          \
+    hipError_t e_ = hipGetLastError();          \
+    if (e_ != hipSuccess) return (int)e_;       \
+  } while (0)
+
+namespace kx {
+
+constexpr int kWave = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+// ---- DPP cross-lane moves inside a 16-lane row ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;  // every lane of the 16-lane row holds the row's sum
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+
+// xor-16 / xor-32 lane exchange (across DPP rows)
+__device__ __forceinline__ float lane_xor16(float v) {
+  // ds_swizzle bit-mode: and_mask=0x1F, or_mask=0, xor_mask=0x10 -> within each 32-lane half
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (0x10 << 10) | 0x1F));
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_ds_bpermute(((lane ^ 32) << 2), __builtin_bit_cast(int, v)));
+}
+
+// Full 64-lane sum; every lane receives it.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += lane_xor16(v);
+  v += lane_xor32(v);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, lane_xor16(v));
+  v = fmaxf(v, lane_xor32(v));
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+}  // namespace kx

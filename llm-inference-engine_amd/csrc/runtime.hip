@@ -1,0 +1,175 @@
+// Thin HIP runtime wrapper behind the C ABI: device memory, copies, streams, events, graphs.
+// Stands in for the reference's CUDADeviceAllocator (kuiper/source/base/alloc_cu.cpp), the memcpy
+// and memset paths of DeviceAllocator (alloc.cpp) and the stream pair of CudaConfig
+// (kuiper/include/base/cuda_config.h:6-17).  No pooling: the token path allocates once.
+#include <string.h>
+
+#include "kx_common.hpp"
+
+extern "C" const char* kx_error_string(int code) {
+  switch (code) {
+    case KX_OK: return "ok";
+    case KX_EINVAL: return "kx: invalid argument";
+    case KX_EUNSUPPORTED: return "kx: unsupported shape";
+    case KX_EWORKSPACE: return "kx: workspace too small";
+    default: break;
+  }
+  if (code >= 10000) return "kx: RCCL call failed (code - 10000 is the ncclResult_t)";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "kx: unknown error";
+}
+
+extern "C" int kx_device_count(int* count) {
+  if (!count) return KX_EINVAL;
+  KX_HIP_TRY(hipGetDeviceCount(count));
+  return KX_OK;
+}
+extern "C" int kx_set_device(int device) {
+  KX_HIP_TRY(hipSetDevice(device));
+  return KX_OK;
+}
+extern "C" int kx_get_device(int* device) {
+  if (!device) return KX_EINVAL;
+  KX_HIP_TRY(hipGetDevice(device));
+  return KX_OK;
+}
+extern "C" int kx_device_name(char* buf, size_t buf_bytes) {
+  if (!buf || buf_bytes == 0) return KX_EINVAL;
+  int dev = 0;
+  KX_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  KX_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  snprintf(buf, buf_bytes, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+           prop.multiProcessorCount);
+  return KX_OK;
+}
+
+extern "C" int kx_malloc(void** ptr, size_t bytes) {
+  if (!ptr) return KX_EINVAL;
+  *ptr = nullptr;
+  if (bytes == 0) return KX_OK;
+  KX_HIP_TRY(hipMalloc(ptr, bytes));
+  return KX_OK;
+}
+extern "C" int kx_free(void* ptr) {
+  if (!ptr) return KX_OK;
+  KX_HIP_TRY(hipFree(ptr));
+  return KX_OK;
+}
+extern "C" int kx_memset(void* ptr, int value, size_t bytes, void* stream) {
+  if (!ptr && bytes) return KX_EINVAL;
+  if (bytes == 0) return KX_OK;
+  KX_HIP_TRY(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
+  return KX_OK;
+}
+
+static int copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, void* stream) {
+  if (bytes == 0) return KX_OK;
+  if (!dst || !src) return KX_EINVAL;
+  if (stream) {
+    KX_HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream));
+  } else {
+    KX_HIP_TRY(hipMemcpy(dst, src, bytes, kind));
+  }
+  return KX_OK;
+}
+extern "C" int kx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  return copy(dst, src, bytes, hipMemcpyHostToDevice, stream);
+}
+extern "C" int kx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  return copy(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+}
+extern "C" int kx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  return copy(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+}
+extern "C" int kx_host_alloc_pinned(void** ptr, size_t bytes) {
+  if (!ptr) return KX_EINVAL;
+  KX_HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+  return KX_OK;
+}
+extern "C" int kx_host_free_pinned(void* ptr) {
+  if (!ptr) return KX_OK;
+  KX_HIP_TRY(hipHostFree(ptr));
+  return KX_OK;
+}
+
+extern "C" int kx_stream_create(void** stream) {
+  if (!stream) return KX_EINVAL;
+  hipStream_t s;
+  KX_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return KX_OK;
+}
+extern "C" int kx_stream_destroy(void* stream) {
+  if (!stream) return KX_OK;
+  KX_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return KX_OK;
+}
+extern "C" int kx_stream_sync(void* stream) {
+  KX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return KX_OK;
+}
+extern "C" int kx_device_sync(void) {
+  KX_HIP_TRY(hipDeviceSynchronize());
+  return KX_OK;
+}
+
+extern "C" int kx_event_create(void** event) {
+  if (!event) return KX_EINVAL;
+  hipEvent_t e;
+  KX_HIP_TRY(hipEventCreate(&e));
+  *event = e;
+  return KX_OK;
+}
+extern "C" int kx_event_destroy(void* event) {
+  if (!event) return KX_OK;
+  KX_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return KX_OK;
+}
+extern "C" int kx_event_record(void* event, void* stream) {
+  if (!event) return KX_EINVAL;
+  KX_HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return KX_OK;
+}
+extern "C" int kx_event_sync(void* event) {
+  if (!event) return KX_EINVAL;
+  KX_HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+  return KX_OK;
+}
+extern "C" int kx_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return KX_EINVAL;
+  KX_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return KX_OK;
+}
+extern "C" int kx_stream_wait_event(void* stream, void* event) {
+  if (!event) return KX_EINVAL;
+  KX_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return KX_OK;
+}
+
+extern "C" int kx_graph_begin_capture(void* stream) {
+  if (!stream) return KX_EINVAL;  // the legacy default stream cannot be captured
+  KX_HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return KX_OK;
+}
+extern "C" int kx_graph_end_capture(void* stream, void** graph_exec) {
+  if (!stream || !graph_exec) return KX_EINVAL;
+  hipGraph_t g = nullptr;
+  KX_HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return (int)e;
+  *graph_exec = ge;
+  return KX_OK;
+}
+extern "C" int kx_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) return KX_EINVAL;
+  KX_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return KX_OK;
+}
+extern "C" int kx_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return KX_OK;
+  KX_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return KX_OK;
+}

@@ -1,0 +1,261 @@
+"""ctypes binding of libkx_hip.so (the C ABI declared in include/kx_hip.h).
+
+This is FFI plumbing for the tests and the benchmark driver: numpy arrays in, device buffers
+handled through the library's own allocator.  There is no CPU fallback anywhere in this
+package: if the shared library is missing or a call fails, a KxError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libkx_hip.so")
+
+ROPE_INTERLEAVED = 0
+ROPE_HALF_SPLIT = 1
+
+
+class KxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/kx_hip.h one to one
+_vp, _i32, _sz, _f = C.c_void_p, C.c_int32, C.c_size_t, C.c_float
+SIGNATURES = {
+    "kx_error_string": (C.c_char_p, [C.c_int]),
+    "kx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "kx_set_device": (C.c_int, [C.c_int]),
+    "kx_get_device": (C.c_int, [C.POINTER(C.c_int)]),
+    "kx_device_name": (C.c_int, [C.c_char_p, _sz]),
+    "kx_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
+    "kx_free": (C.c_int, [_vp]),
+    "kx_memset": (C.c_int, [_vp, C.c_int, _sz, _vp]),
+    "kx_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "kx_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "kx_memcpy_d2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "kx_host_alloc_pinned": (C.c_int, [C.POINTER(_vp), _sz]),
+    "kx_host_free_pinned": (C.c_int, [_vp]),
+    "kx_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "kx_stream_destroy": (C.c_int, [_vp]),
+    "kx_stream_sync": (C.c_int, [_vp]),
+    "kx_device_sync": (C.c_int, []),
+    "kx_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "kx_event_destroy": (C.c_int, [_vp]),
+    "kx_event_record": (C.c_int, [_vp, _vp]),
+    "kx_event_sync": (C.c_int, [_vp]),
+    "kx_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(_f)]),
+    "kx_stream_wait_event": (C.c_int, [_vp, _vp]),
+    "kx_graph_begin_capture": (C.c_int, [_vp]),
+    "kx_graph_end_capture": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "kx_graph_launch": (C.c_int, [_vp, _vp]),
+    "kx_graph_destroy": (C.c_int, [_vp]),
+    "kx_gemv_w8_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "kx_gemv_w8_f32_ex": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
+                                    _i32, _vp]),
+    "kx_gemv_w8_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "kx_gemv_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
+    "kx_gemm_w8_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "kx_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
+    "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                    _vp, _sz, _vp]),
+    "kx_flash_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                         _i32, _f, _i32, _vp, _sz, _vp]),
+    "kx_rmsnorm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
+    "kx_sin_cos_cache_f32": (C.c_int, [_i32, _i32, _f, _vp, _vp, _vp]),
+    "kx_rope_f32": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "kx_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "kx_add_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "kx_embedding_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "kx_argmax_f32": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "kx_comm_unique_id": (C.c_int, [_vp]),
+    "kx_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32]),
+    "kx_comm_destroy": (C.c_int, [_vp]),
+    "kx_comm_allreduce_sum_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "kx_comm_broadcast_f32": (C.c_int, [_vp, _vp, _vp, _sz, _i32, _vp]),
+    "kx_comm_allgather_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+}
+
+
+def lib():
+    """Loads libkx_hip.so; raises KxError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KxError(f"{LIB_PATH} is missing: build it with `make -C llm-inference-engine_amd` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().kx_error_string(rc).decode()
+        raise KxError(f"{what} failed: rc={rc} ({msg})")
+
+
+class Buf:
+    """Owning device buffer from kx_malloc."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().kx_malloc(C.byref(p), max(self.nbytes, 1)), "kx_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        b.dtype, b.shape = a.dtype, a.shape
+        if a.nbytes:
+            check(lib().kx_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, None), "h2d")
+        return b
+
+    @classmethod
+    def zeros(cls, shape, dtype=np.float32):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        b = cls(n)
+        b.dtype, b.shape = np.dtype(dtype), tuple(np.atleast_1d(shape))
+        check(lib().kx_memset(b.ptr, 0, n, None), "memset")
+        check(lib().kx_device_sync(), "sync")
+        return b
+
+    def upload(self, a, byte_offset=0):
+        a = np.ascontiguousarray(a)
+        assert byte_offset + a.nbytes <= self.nbytes
+        check(lib().kx_memcpy_h2d(self.ptr + byte_offset, a.ctypes.data, a.nbytes, None), "h2d")
+
+    def numpy(self, dtype=None, shape=None):
+        dtype = np.dtype(dtype or getattr(self, "dtype", np.uint8))
+        shape = shape if shape is not None else getattr(self, "shape", (self.nbytes // dtype.itemsize,))
+        out = np.empty(shape, dtype)
+        check(lib().kx_device_sync(), "sync")
+        if out.nbytes:
+            check(lib().kx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None), "d2h")
+        return out
+
+    def at(self, byte_offset):
+        return self.ptr + int(byte_offset)
+
+    def free(self):
+        if self.ptr:
+            lib().kx_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_name():
+    b = C.create_string_buffer(256)
+    check(lib().kx_device_name(b, 256), "kx_device_name")
+    return b.value.decode()
+
+
+def sync():
+    check(lib().kx_device_sync(), "kx_device_sync")
+
+
+class Stream:
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().kx_stream_create(C.byref(p)), "kx_stream_create")
+        self.ptr = p.value
+
+    def sync(self):
+        check(lib().kx_stream_sync(self.ptr), "kx_stream_sync")
+
+    def __del__(self):
+        try:
+            lib().kx_stream_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().kx_event_create(C.byref(p)), "kx_event_create")
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        check(lib().kx_event_record(self.ptr, stream), "kx_event_record")
+
+    def sync(self):
+        check(lib().kx_event_sync(self.ptr), "kx_event_sync")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        check(lib().kx_event_elapsed_ms(self.ptr, stop.ptr, C.byref(ms)), "kx_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().kx_event_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+# ---------------- numpy-in / numpy-out conveniences used by the parity tests ----------------
+def gemv_w8(x, w, s, group_size=64):
+    K, M = w.shape
+    dx, dw, ds = Buf.from_numpy(x.astype(np.float32)), Buf.from_numpy(w.astype(np.int8)), \
+        Buf.from_numpy(s.astype(np.float32))
+    dy = Buf.zeros(K)
+    check(lib().kx_gemv_w8_f32(dx.ptr, dw.ptr, ds.ptr, group_size, dy.ptr, M, K, None),
+          "kx_gemv_w8_f32")
+    return dy.numpy(np.float32, (K,))
+
+
+def gemv_f32(x, w, scale=1.0):
+    K, M = w.shape
+    dx, dw = Buf.from_numpy(x.astype(np.float32)), Buf.from_numpy(w.astype(np.float32))
+    dy = Buf.zeros(K)
+    check(lib().kx_gemv_f32(dx.ptr, dw.ptr, dy.ptr, M, K, scale, None), "kx_gemv_f32")
+    return dy.numpy(np.float32, (K,))
+
+
+def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspace_bytes=None):
+    L, S, kv_dim = kc.shape
+    dq, dk, dv = Buf.from_numpy(q.astype(np.float32)), Buf.from_numpy(kc.astype(np.float32)), \
+        Buf.from_numpy(vc.astype(np.float32))
+    out = Buf.zeros(head_num * head_size)
+    if workspace_bytes is None:
+        workspace_bytes = max(lib().kx_attn_workspace_bytes(head_num, head_size),
+                              head_num * S * 4)
+    ws = Buf(workspace_bytes) if workspace_bytes else None
+    check(lib().kx_mha_decode_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos, head_num, kv_mul, head_size,
+                                  kv_dim, S, layer_index, ws.ptr if ws else None, workspace_bytes,
+                                  None), "kx_mha_decode_f32")
+    return out.numpy(np.float32, (head_num, head_size))
+
+
+def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx, softmax_scale=None,
+                    is_causal=True):
+    L, S, kv_dim = kc.shape
+    q = np.ascontiguousarray(q, np.float32).reshape(-1, head_num, head_size)
+    Tq = q.shape[0]
+    if softmax_scale is None:
+        softmax_scale = float(1.0 / np.sqrt(np.float32(head_size)))
+    dq, dk, dv = Buf.from_numpy(q), Buf.from_numpy(kc.astype(np.float32)), \
+        Buf.from_numpy(vc.astype(np.float32))
+    out = Buf.zeros(q.size)
+    wsb = max(lib().kx_attn_workspace_bytes(head_num, head_size), head_num * S * 4)
+    ws = Buf(wsb)
+    check(lib().kx_flash_attention_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, Tq, head_num, kv_head_num,
+                                       head_size, S, pos, layer_idx, softmax_scale,
+                                       1 if is_causal else 0, ws.ptr, wsb, None),
+          "kx_flash_attention_f32")
+    return out.numpy(np.float32, q.shape)

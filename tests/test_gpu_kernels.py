@@ -1,0 +1,322 @@
+"""GPU parity tests: every kernel entry of the C ABI against the CPU oracle on identical seeded
+inputs, against the committed golden fixtures, and through size-independent properties at
+full model sizes.  Tolerances are stated per test; fp32 FMA paths use
+|got - oracle| <= 1e-5 * sum|terms| (the reference's own CPU-vs-CUDA tests use 1e-5:
+test/test_op/test_cu_rmsnorm.cpp:37)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kx  # noqa: E402
+from oracle import kxo  # noqa: E402
+
+GS = 64
+
+
+def rand_w8(rng, K, M, gs=GS):
+    w = rng.integers(-127, 128, size=(K, M), dtype=np.int8)
+    s = rng.uniform(1e-4, 3e-4, size=(K * M) // gs).astype(np.float32)
+    x = rng.standard_normal(M).astype(np.float32)
+    return x, w, s
+
+
+def w8_abs_sum(x, w, s, gs=GS):
+    K, M = w.shape
+    sd = np.repeat(s.astype(np.float64), gs).reshape(K, M)
+    return (np.abs(x.astype(np.float64))[None, :] * sd * np.abs(w.astype(np.float64))).sum(1)
+
+
+# ------------------------------- W8 GEMV -----------------------------------------------------
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_gemv_w8_golden(golden, name):
+    g = golden("g1_quant_gemv.npz")
+    x, q, s = g[f"{name}_x"], g[f"{name}_q"], g[f"{name}_s"]
+    y = kx.gemv_w8(x, q, s, GS)
+    tol = 1e-5 * w8_abs_sum(x, q, s)
+    assert np.all(np.abs(y - g[f"{name}_y64"]) <= tol)
+
+
+@pytest.mark.parametrize("K,M", [(1, 64), (3, 64), (7, 192), (64, 1024), (130, 2048), (512, 2048),
+                                 (33, 3584), (256, 4096), (17, 14336), (8, 18944), (5, 28672),
+                                 (2048, 2048)])
+def test_gemv_w8_vs_oracle(K, M):
+    rng = np.random.default_rng(K * 100003 + M)
+    x, w, s = rand_w8(rng, K, M)
+    want = kxo.gemv_w8(x, w, s, GS)
+    got = kx.gemv_w8(x, w, s, GS)
+    assert np.all(np.abs(got - want) <= 1e-5 * w8_abs_sum(x, w, s))
+
+
+@pytest.mark.parametrize("K,M,gs", [(6, 100, 50), (4, 48, 32), (9, 36, 12), (4, 200, 16)])
+def test_gemv_w8_generic_groups(K, M, gs):
+    # group sizes / row lengths the fast path does not take; groups may straddle rows
+    rng = np.random.default_rng(gs)
+    x, w, s = rand_w8(rng, K, M, gs)
+    want = kxo.gemv_w8(x, w, s, gs)
+    got = kx.gemv_w8(x, w, s, gs)
+    assert np.all(np.abs(got - want) <= 1e-5 * w8_abs_sum(x, w, s, gs))
+
+
+def test_gemv_w8_preconditions():
+    L = kx.lib()
+    b = kx.Buf(4096)
+    assert L.kx_gemv_w8_f32(b.ptr, b.ptr, b.ptr, 64, b.ptr, 6, 4, None) == -1  # M % 4 != 0
+    assert L.kx_gemv_w8_f32(None, b.ptr, b.ptr, 64, b.ptr, 64, 4, None) == -1
+    assert L.kx_gemv_w8_f32(b.ptr, b.ptr, b.ptr, 0, b.ptr, 64, 4, None) == -1
+
+
+def test_gemv_w8_ex_routing_bias_residual():
+    rng = np.random.default_rng(5)
+    dim, kvd = 512, 128
+    K = dim + 2 * kvd
+    x, w, s = rand_w8(rng, K, dim)
+    bias = rng.standard_normal(K).astype(np.float32) * 1e-2
+    want = kxo.gemv_w8(x, w, s, GS) + bias
+    dx, dw, ds, db = map(kx.Buf.from_numpy, (x, w, s, bias))
+    y0, y1, y2 = kx.Buf.zeros(dim), kx.Buf.zeros(kvd), kx.Buf.zeros(kvd)
+    kx.check(kx.lib().kx_gemv_w8_f32_ex(dx.ptr, dw.ptr, ds.ptr, GS, y0.ptr, y1.ptr, y2.ptr, dim,
+                                        dim + kvd, db.ptr, None, dim, K, None))
+    got = np.concatenate([y0.numpy(), y1.numpy(), y2.numpy()])
+    assert np.all(np.abs(got - want) <= 1e-5 * w8_abs_sum(x, w, s) + 1e-7)
+    # residual add in place: y = W x + y
+    res = rng.standard_normal(dim).astype(np.float32)
+    dy = kx.Buf.from_numpy(res)
+    kx.check(kx.lib().kx_gemv_w8_f32_ex(dx.ptr, dw.ptr, ds.ptr, GS, dy.ptr, None, None, dim, dim,
+                                        None, dy.ptr, dim, dim, None))
+    want2 = kxo.gemv_w8(x, w[:dim], s[:dim * dim // GS], GS) + res
+    assert np.all(np.abs(dy.numpy() - want2) <= 1e-5 * w8_abs_sum(x, w[:dim], s[:dim * dim // GS])
+                  + 1e-6)
+
+
+@pytest.mark.parametrize("H,M", [(256, 512), (1000, 2048), (344, 4096)])
+def test_gemv_w8_swiglu(H, M):
+    rng = np.random.default_rng(H)
+    x, w, s = rand_w8(rng, 2 * H, M)
+    s *= 20  # push gate values into the non-linear part of the sigmoid
+    full = kxo.gemv_w8(x, w, s, GS)
+    want = kxo.swiglu(full[:H], full[H:])
+    dx, dw, ds = map(kx.Buf.from_numpy, (x, w, s))
+    out = kx.Buf.zeros(H)
+    kx.check(kx.lib().kx_gemv_w8_swiglu_f32(dx.ptr, dw.ptr, ds.ptr, GS, out.ptr, M, H, None))
+    a = w8_abs_sum(x, w, s)
+    # d(silu(g)*u) <= |u| dg * 1.1 + |silu(g)| du
+    tol = 1e-5 * (1.1 * np.abs(full[H:]) * a[:H] + np.abs(full[:H]) * a[H:]) + 1e-7
+    assert np.all(np.abs(out.numpy() - want) <= tol)
+
+
+def test_gemv_w8_full_size_linearity():
+    # Llama-3-8B w1 shape: W(x1 + 2*x2) == W x1 + 2 W x2 and a row-subset check against the oracle
+    rng = np.random.default_rng(11)
+    K, M = 14336, 4096
+    x1, w, s = rand_w8(rng, K, M)
+    x2 = rng.standard_normal(M).astype(np.float32)
+    dw, ds = kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)
+
+    def run(x):
+        dx, dy = kx.Buf.from_numpy(x), kx.Buf.zeros(K)
+        kx.check(kx.lib().kx_gemv_w8_f32(dx.ptr, dw.ptr, ds.ptr, GS, dy.ptr, M, K, None))
+        return dy.numpy()
+    y1, y2, y12 = run(x1), run(x2), run(x1 + 2 * x2)
+    a = w8_abs_sum(np.abs(x1) + 2 * np.abs(x2), w, s)
+    assert np.all(np.abs(y12 - (y1 + 2 * y2)) <= 3e-5 * a)
+    rows = rng.choice(K, 64, replace=False)
+    for r in rows:
+        want = kxo.gemv_w8(x1, w[r:r + 1], s[r * M // GS:(r + 1) * M // GS], GS)[0]
+        assert abs(y1[r] - want) <= 1e-5 * w8_abs_sum(x1, w[r:r + 1], s[r * M // GS:(r + 1) * M // GS])
+
+
+# ------------------------------- fp32 GEMV ---------------------------------------------------
+def test_gemv_f32_reference_known_answers():
+    # test/test_op/test_cu_matmul.cpp:48-106
+    w = np.arange(1, 10, dtype=np.float32).reshape(3, 3)
+    assert kx.gemv_f32(np.array([1, 1, -1], np.float32), w).tolist() == [0.0, 3.0, 6.0]
+    # test_cu_matmul.cpp:10-46
+    w = np.arange(16, dtype=np.float32).reshape(4, 4)
+    x = np.arange(4, dtype=np.float32)
+    assert kx.gemv_f32(x, w).tolist() == (w @ x).tolist()
+    # test/test_op/test_load.cpp:97-105
+    w = np.arange(2048, dtype=np.float32).reshape(16, 128)
+    y = kx.gemv_f32(np.ones(128, np.float32), w)
+    assert y[0] == 8128 and y[1] == 24512 and y[14] == 237504 and y[15] == 253888
+
+
+@pytest.mark.parametrize("K,M", [(5, 7), (768, 768), (2048, 768), (768, 2048), (1000, 4100),
+                                 (3, 16384)])
+def test_gemv_f32_vs_oracle(K, M):
+    rng = np.random.default_rng(K + M)
+    w = rng.standard_normal((K, M)).astype(np.float32)
+    x = rng.standard_normal(M).astype(np.float32)
+    want = kxo.gemv_f32(x, w, 0.5)
+    got = kx.gemv_f32(x, w, 0.5)
+    tol = 1e-5 * (np.abs(w.astype(np.float64)) @ np.abs(x.astype(np.float64))) * 0.5
+    assert np.all(np.abs(got - want) <= tol)
+
+
+# ------------------------------- decode attention ----------------------------------------------
+def _attn_cases(g):
+    for i in range(int(g["n_cases"])):
+        meta = g[f"c{i}_meta"]
+        cid = int(meta[8])
+        yield f"c{i}", meta, g[f"c{i}_q"], g[f"cache{cid}_k"], g[f"cache{cid}_v"], g[f"c{i}_out"]
+    yield "ref", g["ref_meta"], g["ref_q"], g["ref_kc"], g["ref_vc"], g["ref_out"]
+
+
+def test_mha_decode_golden(golden):
+    g = golden("g5_attention.npz")
+    ran = 0
+    for name, meta, q, kc, vc, want in _attn_cases(g):
+        H, KVH, hs, S, pos, Tq, L, layer = [int(v) for v in meta[:8]]
+        if Tq != 1:
+            continue
+        got = kx.mha_decode(q.reshape(-1), kc, vc, pos, H, H // KVH, hs, layer)
+        np.testing.assert_allclose(got.reshape(1, H, hs), want, rtol=0, atol=1e-5, err_msg=name)
+        ran += 1
+    assert ran >= 5
+
+
+def test_mha_decode_reference_test_inputs_row_by_row(golden):
+    # test/test_op/test_flash_attention.cpp:38-81 geometry (head_size 8 -> generic kernel)
+    g = golden("g5_attention.npz")
+    H, KVH, hs, S, pos, Tq, L, layer = [int(v) for v in g["ref_meta"][:8]]
+    for i in range(Tq):
+        got = kx.mha_decode(g["ref_q"][i].reshape(-1), g["ref_kc"], g["ref_vc"], i, H, 1, hs, 0)
+        np.testing.assert_allclose(got, g["ref_out"][i], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("H,KVH,hs,S,pos", [
+    (12, 12, 64, 256, 0), (12, 12, 64, 256, 15), (12, 12, 64, 256, 16), (12, 12, 64, 256, 255),
+    (32, 8, 64, 600, 599), (32, 8, 128, 2100, 2047), (28, 4, 128, 700, 650), (64, 8, 128, 300, 17),
+    (4, 2, 32, 32, 31), (8, 1, 64, 130, 129), (40, 2, 64, 64, 63)])
+def test_mha_decode_vs_oracle(H, KVH, hs, S, pos):
+    rng = np.random.default_rng(H * 7 + pos)
+    L, layer = 2, 1
+    kc = rng.standard_normal((L, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((L, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    want = kxo.mha(pos, H, layer, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, layer)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_mha_decode_forced_rescale_and_no_workspace():
+    # one key far above the rest late in the sequence forces the online-softmax rescale branch;
+    # with no workspace the kernel must fall back to a single split and still be right
+    rng = np.random.default_rng(3)
+    H, KVH, hs, S, pos = 8, 2, 128, 512, 500
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32) * 0.1
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    kc[0, 333, :hs] = q[:hs] * 3.0   # spike for heads sharing kv head 0
+    want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    for wsb in (None, 0):
+        got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0, workspace_bytes=wsb)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_mha_decode_ignores_rows_past_pos():
+    rng = np.random.default_rng(4)
+    H, KVH, hs, S, pos = 8, 2, 64, 128, 37
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    a = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    kc[0, pos + 1:] = np.nan
+    vc[0, pos + 1:] = np.inf
+    b = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    assert np.array_equal(a, b)
+
+
+# ------------------------------- support kernels -------------------------------------------------
+def _run(fn, *args):
+    kx.check(fn(*args))
+    kx.sync()
+
+
+@pytest.mark.parametrize("dim,rows,eps", [(768, 1, 1e-5), (4096, 3, 1e-5), (3584, 2, 1e-6),
+                                          (130, 1, 1e-5)])
+def test_rmsnorm(dim, rows, eps):
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((rows, dim)).astype(np.float32)
+    w = rng.standard_normal(dim).astype(np.float32)
+    dx, dw, do = kx.Buf.from_numpy(x), kx.Buf.from_numpy(w), kx.Buf.zeros((rows, dim))
+    _run(kx.lib().kx_rmsnorm_f32, dx.ptr, dw.ptr, do.ptr, dim, rows, eps, None)
+    want = np.stack([kxo.rmsnorm(x[r], w, eps) for r in range(rows)])
+    np.testing.assert_allclose(do.numpy(), want, rtol=1e-5, atol=1e-6)  # test_cu_rmsnorm.cpp:37
+
+
+@pytest.mark.parametrize("variant,theta,hs", [(0, 1e4, 64), (1, 5e5, 64), (1, 5e5, 128),
+                                              (1, 1e6, 128), (0, 1e4, 32)])
+def test_rope_and_table(variant, theta, hs):
+    rng = np.random.default_rng(int(theta) + hs)
+    H, KVH, S, rows, pos = 8, 2, 64, 3, 20
+    dim, kvd = H * hs, KVH * hs
+    ds_, dc_ = kx.Buf.zeros((S, hs)), kx.Buf.zeros((S, hs))
+    _run(kx.lib().kx_sin_cos_cache_f32, hs, S, theta, ds_.ptr, dc_.ptr, None)
+    s_want, c_want = kxo.sin_cos_cache(hs, S, theta)
+    # device powf/sinf/cosf vs libm: the reference's own rope test uses 1e-3 (test_cu_rope.cpp:43)
+    np.testing.assert_allclose(ds_.numpy(), s_want, atol=2e-4)
+    np.testing.assert_allclose(dc_.numpy(), c_want, atol=2e-4)
+    # rotate with the ORACLE's tables so the rotation itself is checked tightly
+    ds_.upload(s_want)
+    dc_.upload(c_want)
+    q = rng.standard_normal((rows, dim)).astype(np.float32)
+    k_stride = kvd + 16
+    k = rng.standard_normal((rows, k_stride)).astype(np.float32)
+    dq, dk = kx.Buf.from_numpy(q), kx.Buf.from_numpy(k)
+    _run(kx.lib().kx_rope_f32, variant, dim, kvd, hs, dq.ptr, dk.ptr, k_stride, pos, rows, ds_.ptr,
+         dc_.ptr, None)
+    gq, gk = dq.numpy(), dk.numpy()
+    for r in range(rows):
+        wq, wk = kxo.rope(variant, dim, kvd, hs, q[r], k[r, :kvd], pos + r, s_want, c_want)
+        np.testing.assert_allclose(gq[r], wq, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(gk[r, :kvd], wk, rtol=1e-6, atol=1e-6)
+        assert np.array_equal(gk[r, kvd:], k[r, kvd:])  # padding between rows untouched
+
+
+def test_swiglu_add_embedding_argmax():
+    rng = np.random.default_rng(9)
+    n = 14336
+    a = rng.standard_normal(n).astype(np.float32) * 3
+    b = rng.standard_normal(n).astype(np.float32)
+    da, db, do = kx.Buf.from_numpy(a), kx.Buf.from_numpy(b), kx.Buf.zeros(n)
+    _run(kx.lib().kx_swiglu_f32, da.ptr, db.ptr, do.ptr, n, None)
+    np.testing.assert_allclose(do.numpy(), kxo.swiglu(a, b), rtol=1e-5, atol=1e-6)  # test_cu_swiglu.cpp:39
+    _run(kx.lib().kx_add_f32, da.ptr, db.ptr, do.ptr, n, None)
+    assert np.array_equal(do.numpy(), a + b)
+    table = rng.standard_normal((1000, 768)).astype(np.float32)
+    toks = np.array([5, 999, 0, 5], np.int32)
+    dt, dtok, dout = kx.Buf.from_numpy(table), kx.Buf.from_numpy(toks), kx.Buf.zeros((4, 768))
+    _run(kx.lib().kx_embedding_f32, dtok.ptr, 4, dt.ptr, 768, 1000, dout.ptr, None)
+    assert np.array_equal(dout.numpy(), table[toks])
+    for nn in (1, 63, 1024, 128256):
+        lg = rng.standard_normal(nn).astype(np.float32)
+        if nn > 100:
+            lg[77] = lg[90] = 50.0  # tie: first maximum wins
+        dl, di = kx.Buf.from_numpy(lg), kx.Buf.zeros(1, np.int32)
+        _run(kx.lib().kx_argmax_f32, dl.ptr, nn, di.ptr, None)
+        assert int(di.numpy()[0]) == kxo.argmax(lg)
+
+
+def test_streams_events_graph_replay():
+    rng = np.random.default_rng(1)
+    K, M = 256, 1024
+    x, w, s = rand_w8(rng, K, M)
+    dx, dw, ds, dy = kx.Buf.from_numpy(x), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s), kx.Buf.zeros(K)
+    st = kx.Stream()
+    L = kx.lib()
+    kx.check(L.kx_graph_begin_capture(st.ptr))
+    kx.check(L.kx_gemv_w8_f32(dx.ptr, dw.ptr, ds.ptr, GS, dy.ptr, M, K, st.ptr))
+    ge = C.c_void_p()
+    kx.check(L.kx_graph_end_capture(st.ptr, C.byref(ge)))
+    assert np.all(dy.numpy() == 0)  # capture records, it does not run
+    e0, e1 = kx.Event(), kx.Event()
+    e0.record(st.ptr)
+    kx.check(L.kx_graph_launch(ge, st.ptr))
+    e1.record(st.ptr)
+    e1.sync()
+    assert e0.elapsed_ms(e1) >= 0
+    assert np.all(np.abs(dy.numpy() - kxo.gemv_w8(x, w, s, GS)) <= 1e-5 * w8_abs_sum(x, w, s))
+    kx.check(L.kx_graph_destroy(ge))
