@@ -94,6 +94,40 @@ int kx_gemv_w8_f32_ex(const float* x, const int8_t* w, const float* scales, int3
 int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const float* scales13,
                           int32_t group_size, float* out, int32_t M, int32_t H, void* stream);
 
+/* The general fused form behind the three entries above, plus the fusions the token loop uses:
+ * RMSNorm of x while it is staged (rmsnorm_kernel.cu:62-108 + llama3.cpp:637-646,755-759) and,
+ * for mode KX_GEMV_QKV_ROPE, RoPE on the finished q/k rotation pairs (rope_kernel.cu) with k and
+ * v written into their KV-cache row: y1/y2 point at the layer's [seq_len][kv_dim] block and are
+ * advanced by pos*kv_pos_stride floats (model.cpp:237-245).  `pos_dev` (device int32) is read
+ * by the kernel when non-null, so a captured graph can be replayed as the position advances;
+ * otherwise `pos` is used.  Unused pointer fields are NULL, unused ints 0. */
+enum { KX_GEMV_PLAIN = 0, KX_GEMV_GATE_UP = 1, KX_GEMV_QKV_ROPE = 2 };
+typedef struct kx_gemv_w8_desc {
+  int32_t mode;         /* KX_GEMV_* */
+  int32_t group_size;
+  int32_t M, K;         /* K counts all stacked rows (2*H for KX_GEMV_GATE_UP) */
+  const float* x;
+  const int8_t* w;
+  const float* scales;
+  const float* norm_w;  /* nullable: fused input RMSNorm weight [M] */
+  float norm_eps;
+  float* y0;            /* rows [0,k0)  (all rows when y1/y2 are NULL) */
+  float* y1;            /* rows [k0,k1) */
+  float* y2;            /* rows [k1,K)  */
+  int32_t k0, k1;
+  const float* bias;     /* nullable [K] */
+  const float* residual; /* nullable [K], KX_GEMV_PLAIN only; may alias y0 */
+  /* KX_GEMV_QKV_ROPE */
+  const float* sin_cache;
+  const float* cos_cache;
+  const int32_t* pos_dev;
+  int32_t pos;
+  int32_t rope_variant;  /* KX_ROPE_* */
+  int32_t head_size;
+  int32_t kv_pos_stride;
+} kx_gemv_w8_desc;
+int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* desc, void* stream);
+
 /* ---------------- fp32 GEMV ----------------
  * Replaces matmul_kernel_cu / matmul_kernel_cu_fp32 (cuda/matmul_kernel.cu:6-54,89-109) and
  * matmul_kernel_cpu (cpu/matmul_kernel.cpp:5-41) behind MatmulKernel (kernels_interface.h:9-10):
@@ -125,6 +159,15 @@ int kx_mha_decode_f32(const float* query, const float* key_cache, const float* v
                       float* out, int32_t pos, int32_t head_num, int32_t kv_mul, int32_t head_size,
                       int32_t kv_dim, int32_t seq_len, int32_t layer_index, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* Same kernel with the position read from device memory (replayable under graph capture);
+ * `max_pos` sizes the grid for the longest context this launch will ever see.  Needs a head
+ * size the tiled kernel is built for (32/64/128) and kv_mul <= 16. */
+int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const float* value_cache,
+                           float* out, const int32_t* pos_dev, int32_t max_pos, int32_t head_num,
+                           int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
+                           int32_t layer_index, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* kx_flash_attention_f32 replaces flash_attention_kernel_cu (cuda/flash_attention_kernel.cu:
  * 214-303) behind FlashAttentionKernel (kernels_interface.h:49-54).  Semantics (the reference
@@ -161,9 +204,28 @@ int kx_add_f32(const float* a, const float* b, float* out, int32_t n, void* stre
 /* emb_kernel_cu (cuda/emb_kernel.cu:3-21): tokens on device. */
 int kx_embedding_f32(const int32_t* tokens, int32_t n_tokens, const float* table, int32_t dim,
                      int32_t vocab_size, float* out, void* stream);
+/* One-token gather with the token taken as history_dev[*pos_dev] (replayable under capture). */
+int kx_embedding_dpos_f32(const int32_t* history_dev, const int32_t* pos_dev, const float* table,
+                          int32_t dim, int32_t vocab_size, float* out, void* stream);
 /* argmax_kernel_cu (cuda/argmax_kernel.cu:49-87): first maximum wins; result written to a
  * caller-provided device int32 (the reference allocates per call). */
 int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index, void* stream);
+
+/* End of one decode step, on the device (post_processing, llama3.cpp:801-813, without the
+ * host round trip): token = argmax(logits); history[pos+1] = token (when history != NULL and in
+ * range); pos += 1. */
+int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev, int32_t* pos_dev,
+                       int32_t* history_dev, int32_t history_len, void* stream);
+
+/* Seeded synthetic tensors generated on the device (the benchmarks run on random-init weights;
+ * the reference reads real checkpoints through mmap, model.cpp:93-115).  dst is a dense
+ * [rows][cols] slice whose element (i, j) is element (row0+i, col0+j) of a global matrix with
+ * leading dimension ld; the value depends only on (seed, global index), so tensor-parallel shards
+ * are slices of one and the same tensor.  int8: uniform in [-127, 127]; f32: uniform in [lo, hi). */
+int kx_fill_hash_i8(int8_t* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0, int64_t col0,
+                    uint64_t seed, void* stream);
+int kx_fill_hash_f32(float* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0,
+                     int64_t col0, uint64_t seed, float lo, float hi, void* stream);
 
 /* ---------------- tensor-parallel communicator ----------------
  * Replaces NcclHandler (kuiper/include/base/nccl_handler.h:29-58, source/base/nccl_handler.cpp:

@@ -28,8 +28,8 @@ __host__ __device__ inline size_t attn_ws_stride(int hs) { return (size_t)hs + 2
 template <int HS>
 __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
-    float* __restrict__ out, float* __restrict__ ws, int last /* = pos */, int kv_mul, int kv_dim,
-    float scale, int tiles_per_split, int nsplit) {
+    float* __restrict__ out, float* __restrict__ ws, int last_val, const int32_t* __restrict__ pos_dev,
+    int kv_mul, int kv_dim, float scale) {
   constexpr int NJ = HS / 16;                 // float4 K loads per lane per tile
   constexpr int NH = HS >= 64 ? HS / 64 : 1;  // 64-dim halves of the output
   constexpr int DLV = HS >= 64 ? 16 : HS / 4; // dim-lanes that carry data
@@ -40,6 +40,13 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int kvh = blockIdx.x, split = blockIdx.y;
+  // The position may live in device memory so a captured launch can be replayed as it advances;
+  // the grid is then sized for the longest context and surplus splits leave at once.
+  const int last = pos_dev ? *pos_dev : last_val;
+  const int ntiles = (last >> 4) + 1;
+  const int tiles_per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int nsplit = (ntiles + tiles_per_split - 1) / tiles_per_split;
+  if (split >= nsplit) return;
   const float* kbase = kc + (size_t)kvh * HS;
   const float* vbase = vc + (size_t)kvh * HS;
 
@@ -60,7 +67,6 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     for (int e = 0; e < 4; ++e) o[h][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (last >> 4) + 1;
   const int t_begin = split * tiles_per_split;
   const int t_end = min(t_begin + tiles_per_split, ntiles);
   for (int t = t_begin + wave; t < t_end; t += kAttnWaves) {
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     if (nsplit == 1) {
       out[(size_t)hq * HS + d] = O / L;
     } else {
-      float* dst = ws + ((size_t)hq * nsplit + split) * attn_ws_stride(HS);
+      float* dst = ws + ((size_t)hq * gridDim.y + split) * attn_ws_stride(HS);
       if (d == 0) {
         dst[0] = M;
         dst[1] = L;
@@ -175,9 +181,15 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
 
 // out[h][d] = sum_s O_s[d] e^{m_s-M} / sum_s l_s e^{m_s-M}
 __global__ void attn_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int hs,
-                                  int nsplit) {
+                                  int nsplit_grid, int last_val,
+                                  const int32_t* __restrict__ pos_dev) {
   const int hq = blockIdx.x;
-  const float* base = ws + (size_t)hq * nsplit * attn_ws_stride(hs);
+  const int last = pos_dev ? *pos_dev : last_val;
+  const int ntiles = (last >> 4) + 1;
+  const int tps = (ntiles + nsplit_grid - 1) / nsplit_grid;
+  const int nsplit = (ntiles + tps - 1) / tps;
+  if (nsplit == 1) return;  // the attention kernel wrote the final rows itself
+  const float* base = ws + (size_t)hq * nsplit_grid * attn_ws_stride(hs);
   float M = -INFINITY;
   for (int s = 0; s < nsplit; ++s) M = fmaxf(M, base[(size_t)s * attn_ws_stride(hs)]);
   for (int d = threadIdx.x; d < hs; d += blockDim.x) {
@@ -243,11 +255,11 @@ extern "C" size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size) {
   return (size_t)head_num * kx::kMaxSplits * kx::attn_ws_stride(head_size) * sizeof(float);
 }
 
-extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
-                                 const float* value_cache, float* out, int32_t pos,
-                                 int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t kv_dim,
-                                 int32_t seq_len, int32_t layer_index, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+static int mha_decode_launch(const float* query, const float* key_cache, const float* value_cache,
+                             float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
+                             int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
+                             int32_t layer_index, void* workspace, size_t workspace_bytes,
+                             void* stream) {
   using namespace kx;
   if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
   if (pos < 0 || pos >= seq_len || head_num <= 0 || kv_mul <= 0 || head_num % kv_mul) return KX_EINVAL;
@@ -263,6 +275,7 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
                      (((uintptr_t)query | (uintptr_t)kc | (uintptr_t)vc) % 16 == 0) &&
                      kv_dim % 4 == 0;
   if (!tiled) {
+    if (pos_dev) return KX_EUNSUPPORTED;
     if (!workspace || workspace_bytes < (size_t)head_num * seq_len * sizeof(float))
       return KX_EWORKSPACE;
     hipLaunchKernelGGL(attn_decode_generic_kernel, dim3(head_num), dim3(256), 0,
@@ -272,6 +285,8 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
     return KX_OK;
   }
 
+  // `pos` sizes the grid: the actual position when passed by value, the largest position the
+  // launch may ever see when it is read from pos_dev.
   const int ntiles = (pos >> 4) + 1;
   // one tile per wave is the finest useful cut; keep the grid near 2 workgroups per CU
   int nsplit = (ntiles + kAttnWaves - 1) / kAttnWaves;
@@ -283,23 +298,23 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
     const size_t fit = workspace ? workspace_bytes / per_split : 0;
     if (fit < (size_t)nsplit) nsplit = fit < 1 ? 1 : (int)fit;
   }
-  int tps = (ntiles + nsplit - 1) / nsplit;
-  nsplit = (ntiles + tps - 1) / tps;  // no empty splits
+  const int tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;  // no empty splits at `pos`
   float* ws = reinterpret_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(kvh, nsplit), block(kAttnWaves * 64);
   switch (head_size) {
     case 32:
       hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, s, query, kc, vc, out, ws, pos,
-                         kv_mul, kv_dim, scale, tps, nsplit);
+                         pos_dev, kv_mul, kv_dim, scale);
       break;
     case 64:
       hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, s, query, kc, vc, out, ws, pos,
-                         kv_mul, kv_dim, scale, tps, nsplit);
+                         pos_dev, kv_mul, kv_dim, scale);
       break;
     case 128:
       hipLaunchKernelGGL(attn_decode_kernel<128>, grid, block, 0, s, query, kc, vc, out, ws, pos,
-                         kv_mul, kv_dim, scale, tps, nsplit);
+                         pos_dev, kv_mul, kv_dim, scale);
       break;
     default:
       return KX_EUNSUPPORTED;
@@ -307,8 +322,30 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
   KX_LAUNCH_CHECK();
   if (nsplit > 1) {
     hipLaunchKernelGGL(attn_merge_kernel, dim3(head_num), dim3(head_size < 64 ? 64 : head_size), 0,
-                       s, ws, out, head_size, nsplit);
+                       s, ws, out, head_size, nsplit, pos, pos_dev);
     KX_LAUNCH_CHECK();
   }
   return KX_OK;
+}
+
+extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
+                                 const float* value_cache, float* out, int32_t pos,
+                                 int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t kv_dim,
+                                 int32_t seq_len, int32_t layer_index, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return mha_decode_launch(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
+                           head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
+                           stream);
+}
+
+extern "C" int kx_mha_decode_dpos_f32(const float* query, const float* key_cache,
+                                      const float* value_cache, float* out,
+                                      const int32_t* pos_dev, int32_t max_pos, int32_t head_num,
+                                      int32_t kv_mul, int32_t head_size, int32_t kv_dim,
+                                      int32_t seq_len, int32_t layer_index, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (!pos_dev) return KX_EINVAL;
+  return mha_decode_launch(query, key_cache, value_cache, out, max_pos, pos_dev, head_num, kv_mul,
+                           head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
+                           stream);
 }

@@ -9,30 +9,21 @@
 // coalesced), the 16 elements of a lane always sit inside one quant group so its scale is one
 // register, x is staged once per workgroup in LDS in a layout that makes the four 16-byte
 // reads per weight load conflict-free, and the row sum is finished with DPP + swizzle.
+// The first batch of weight loads is issued before x is staged so the HBM round trip and the
+// L2 round trip for x overlap.
+//
+// Optional fusions used by the token loop (each replaces a separate launch of the reference):
+//   - RMSNorm of x while staging it           (rmsnorm_kernel.cu:62-108, llama3.cpp:637-646)
+//   - bias / residual add in the epilogue      (matmul.cpp:76-79, llama3.cpp:751-752,787)
+//   - [Wq;Wk;Wv] in one launch with RoPE applied to the finished q/k pairs and k, v written
+//     straight into their KV-cache row        (llama3.cpp:648-677, rope_kernel.cu)
+//   - [W1;W3] in one launch with SwiGLU         (llama3.cpp:761-776, swiglu_kernel.cu:4-22)
 //
 // Rounding order differs from the reference only in where the scale is applied: the 16
 // products x*w of a lane are summed first and the group scale multiplies that partial sum.
-#include "kx_common.hpp"
+#include "gemv_w8.hpp"
 
 namespace kx {
-
-struct GemvW8Args {
-  const float* x;
-  const int8_t* w;
-  const float* scales;
-  float* y0;
-  float* y1;
-  float* y2;
-  const float* bias;
-  const float* residual;
-  int32_t k0, k1;          // row routing: [0,k0)->y0, [k0,k1)->y1, [k1,K)->y2
-  int32_t M, K;
-  int32_t chunks;          // ceil(M / 1024)
-  int32_t gs_shift;        // log2(group_size)
-  int32_t groups_per_row;  // M / group_size
-  int32_t rows_per_block;
-  int32_t swiglu_half;     // >0: rows p and p+swiglu_half are gate/up of output p
-};
 
 __device__ __forceinline__ float dot16(const i32x4 wv, const f32x4 x0, const f32x4 x1,
                                        const f32x4 x2, const f32x4 x3) {
@@ -58,124 +49,234 @@ __device__ __forceinline__ float dot16(const i32x4 wv, const f32x4 x0, const f32
   return a;
 }
 
-__device__ __forceinline__ void store_row(const GemvW8Args& a, int row, float v) {
-  if (a.bias) v += a.bias[row];
-  float* dst;
-  int r = row;
-  if (row < a.k0) {
-    dst = a.y0;
-  } else if (row < a.k1) {
-    dst = a.y1;
-    r = row - a.k0;
-  } else {
-    dst = a.y2;
-    r = row - a.k1;
+// Virtual row v -> matrix row.  With half-split RoPE the two rows of a rotation pair are hs/2
+// apart; the virtual order puts them next to each other so one wave finishes both.
+template <int MODE>
+__device__ __forceinline__ int map_row(const GemvW8Args& a, int v) {
+  if constexpr (MODE == GEMV_QKV_ROPE) {
+    if (a.rope_variant == KX_ROPE_HALF_SPLIT && v < a.k1) {
+      const int hs = a.head_size;
+      const int head = v / hs, i = v - head * hs;
+      return head * hs + (i >> 1) + (i & 1) * (hs >> 1);
+    }
   }
-  if (a.residual) v += a.residual[row];
-  dst[r] = v;
+  return v;
 }
 
-// R rows per wave at a time, U chunk loads per row in flight.  GU: rows p and p+swiglu_half are
-// the gate and up rows of output p (fused [W1;W3] + SwiGLU).
-template <int R, int U, bool GU>
+__device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, float*& dst, int& r) {
+  if (row < a.k0) {
+    dst = a.y0;
+    r = row;
+  } else if (row < a.k1) {
+    dst = a.y1 + (size_t)pos * a.kv_pos_stride;
+    r = row - a.k0;
+  } else {
+    dst = a.y2 + (size_t)pos * a.kv_pos_stride;
+    r = row - a.k1;
+  }
+}
+
+// R rows per wave at a time (R even for GEMV_QKV_ROPE), U chunk loads per row in flight.
+template <int R, int U, int MODE>
 __global__ void gemv_w8_kernel(const GemvW8Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* xs = reinterpret_cast<f32x4*>(smem);
+  __shared__ float red[16];
+  constexpr bool GU = MODE == GEMV_GATE_UP;
+  constexpr int R2 = GU ? R : 1;
+  constexpr int U2 = GU ? U : 1;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int nwaves = blockDim.x >> 6;
   const int M = a.M;
+  const int out_rows = GU ? a.swiglu_half : a.K;
   const int row_begin = blockIdx.x * a.rows_per_block;
-  const int row_end = min(row_begin + a.rows_per_block, GU ? a.swiglu_half : a.K);
+  const int row_end = min(row_begin + a.rows_per_block, out_rows);
+  const int col_lane = lane * 16;
+
+  i32x4 wv[R][U];
+  float sc[R][U];
+  i32x4 wv2[R2][U2];
+  float sc2[R2][U2];
+
+  auto load_batch = [&](int r0, int c0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int col = (c0 + u) * 1024 + col_lane;
+        if (col < M) {
+          const size_t off = (size_t)row * (size_t)M + (size_t)col;
+          wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
+          sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
+                                                (col >> a.gs_shift));
+          if constexpr (GU) {
+            const size_t off2 = off + (size_t)a.swiglu_half * (size_t)M;
+            wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
+            sc2[r][u] = __builtin_nontemporal_load(
+                a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
+          }
+        } else {
+          wv[r][u] = i32x4{0, 0, 0, 0};
+          sc[r][u] = 0.f;
+          if constexpr (GU) {
+            wv2[r][u] = i32x4{0, 0, 0, 0};
+            sc2[r][u] = 0.f;
+          }
+        }
+      }
+    }
+  };
+
+  int r0 = row_begin + wave * R;
+  int c0 = 0;
+  const bool active = r0 < row_end;
+  if (active) load_batch(r0, c0);  // in flight while x is staged
 
   // ---- stage x: slot (c*4+p)*64+l  <-  x[c*1024 + l*16 + p*4 .. +4) ; zero past M ----
   {
     const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
     const int n4 = a.chunks * 256;
     const int m4 = M >> 2;
+    float ss = 0.f;
     for (int i = tid; i < n4; i += blockDim.x) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (i < m4) v = xg[i];
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
       const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
       xs[((c * 4 + p) << 6) + l] = v;
     }
+    if (a.norm_w) {
+      // rmsnorm (cpu/rmsnorm_kernel.cpp:30-32): x <- norm_w * (rsqrt(mean(x^2)+eps) * x)
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      float tot = 0.f;
+      for (int w = 0; w < nwaves; ++w) tot += red[w];
+      const float rs = 1.0f / sqrtf(tot / (float)M + a.norm_eps);
+      const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w);
+      for (int i = tid; i < m4; i += blockDim.x) {
+        const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
+        const int slot = ((c * 4 + p) << 6) + l;
+        const f32x4 v = xs[slot], g = ng[i];
+        xs[slot] = f32x4{g.x * (rs * v.x), g.y * (rs * v.y), g.z * (rs * v.z), g.w * (rs * v.w)};
+      }
+    }
   }
   __syncthreads();
+  if (!active) return;
 
-  const int col_lane = lane * 16;
-  for (int r0 = row_begin + wave * R; r0 < row_end; r0 += nwaves * R) {
-    constexpr int R2 = GU ? R : 1;
-    constexpr int U2 = GU ? U : 1;
-    float total[R];
-    float total2[R2];  // up-projection rows (fused gate/up)
-#pragma unroll
-    for (int r = 0; r < R; ++r) total[r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < R2; ++r) total2[r] = 0.f;
+  int pos = 0;
+  if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
 
-    for (int c0 = 0; c0 < a.chunks; c0 += U) {
-      i32x4 wv[R][U];
-      float sc[R][U];
-      i32x4 wv2[R2][U2];
-      float sc2[R2][U2];
+  float total[R];
+  float total2[R2];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = min(r0 + r, row_end - 1);
+  for (int r = 0; r < R; ++r) total[r] = 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int col = (c0 + u) * 1024 + col_lane;
-          if (col < M) {
-            const size_t off = (size_t)row * (size_t)M + (size_t)col;
-            wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
-            sc[r][u] = __builtin_nontemporal_load(
-                a.scales + (size_t)row * a.groups_per_row + (col >> a.gs_shift));
-            if constexpr (GU) {
-              const size_t off2 = off + (size_t)a.swiglu_half * (size_t)M;
-              wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
-              sc2[r][u] = __builtin_nontemporal_load(
-                  a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row +
-                  (col >> a.gs_shift));
-            }
-          } else {
-            wv[r][u] = i32x4{0, 0, 0, 0};
-            sc[r][u] = 0.f;
-            if constexpr (GU) {
-              wv2[r][u] = i32x4{0, 0, 0, 0};
-              sc2[r][u] = 0.f;
-            }
-          }
-        }
-      }
+  for (int r = 0; r < R2; ++r) total2[r] = 0.f;
+
+  for (;;) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (c0 + u < a.chunks) {
-          const int base = ((c0 + u) * 4) << 6;
-          const f32x4 x0 = xs[base + lane];
-          const f32x4 x1 = xs[base + 64 + lane];
-          const f32x4 x2 = xs[base + 128 + lane];
-          const f32x4 x3 = xs[base + 192 + lane];
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u < a.chunks) {
+        const int base = ((c0 + u) * 4) << 6;
+        const f32x4 x0 = xs[base + lane];
+        const f32x4 x1 = xs[base + 64 + lane];
+        const f32x4 x2 = xs[base + 128 + lane];
+        const f32x4 x3 = xs[base + 192 + lane];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            total[r] = fmaf(dot16(wv[r][u], x0, x1, x2, x3), sc[r][u], total[r]);
-            if constexpr (GU)
-              total2[r] = fmaf(dot16(wv2[r][u], x0, x1, x2, x3), sc2[r][u], total2[r]);
-          }
+        for (int r = 0; r < R; ++r) {
+          total[r] = fmaf(dot16(wv[r][u], x0, x1, x2, x3), sc[r][u], total[r]);
+          if constexpr (GU)
+            total2[r] = fmaf(dot16(wv2[r][u], x0, x1, x2, x3), sc2[r][u], total2[r]);
         }
       }
     }
+    c0 += U;
+    if (c0 < a.chunks) {
+      load_batch(r0, c0);
+      continue;
+    }
+    // ---- row group finished: start the next group's loads, then reduce and store this one ----
+    const int done_r0 = r0;
+    r0 += nwaves * R;
+    c0 = 0;
+    const bool more = r0 < row_end;
+    float fin[R];
+    float fin2[R2];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float v = wave_sum(total[r]);
-      if constexpr (GU) {
-        const float up = wave_sum(total2[r]);
-        // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
-        v = v * (1.0f / (1.0f + expf(-v))) * up;
-      }
-      const int row = r0 + r;
-      if (lane == 0 && row < row_end) store_row(a, row, v);
+      fin[r] = total[r];
+      total[r] = 0.f;
     }
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+      fin2[r] = total2[r];
+      total2[r] = 0.f;
+    }
+    if (more) load_batch(r0, c0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      fin[r] = wave_sum(fin[r]);
+      if constexpr (GU) {
+        const float up = wave_sum(fin2[r]);
+        // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
+        fin[r] = fin[r] * (1.0f / (1.0f + expf(-fin[r]))) * up;
+      }
+    }
+    if (lane == 0) {
+      if constexpr (MODE == GEMV_QKV_ROPE) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+          const int v = done_r0 + r;
+          if (v < row_end) {  // row counts are even, so v+1 is valid too
+            const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
+            float o0 = fin[r], o1 = fin[r + 1];
+            if (a.bias) {
+              o0 += a.bias[row0];
+              o1 += a.bias[row1];
+            }
+            if (v < a.k1) {
+              // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
+              const int hs = a.head_size;
+              const int in_head = row0 % hs;
+              const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
+              const float fci = a.sin_cache[(size_t)pos * hs + tab];
+              const float fcr = a.cos_cache[(size_t)pos * hs + tab];
+              const float t0 = o0 * fcr - o1 * fci;
+              const float t1 = o0 * fci + o1 * fcr;
+              o0 = t0;
+              o1 = t1;
+            }
+            float* dst;
+            int rr;
+            route(a, row0, pos, dst, rr);
+            dst[rr] = o0;
+            route(a, row1, pos, dst, rr);
+            dst[rr] = o1;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int row = done_r0 + r;
+          if (row < row_end) {
+            float v = fin[r];
+            if (a.bias) v += a.bias[row];
+            if (a.residual) v += a.residual[row];
+            float* dst;
+            int rr;
+            route(a, row, 0, dst, rr);
+            dst[rr] = v;
+          }
+        }
+      }
+    }
+    if (!more) break;
   }
 }
 
@@ -198,23 +299,30 @@ __global__ void gemv_w8_generic_kernel(const GemvW8Args a, int32_t group_size) {
     }
   }
   total = wave_sum(total);
-  if (lane == 0) store_row(a, row, total);
+  if (lane == 0) {
+    if (a.bias) total += a.bias[row];
+    if (a.residual) total += a.residual[row];
+    float* dst;
+    int rr;
+    route(a, row, 0, dst, rr);
+    dst[rr] = total;
+  }
 }
 
-template <int R, int U, bool GU>
+template <int R, int U, int MODE>
 static int launch(const GemvW8Args& a, int threads, hipStream_t s) {
-  const int out_rows = GU ? a.swiglu_half : a.K;
+  const int out_rows = MODE == GEMV_GATE_UP ? a.swiglu_half : a.K;
   const int grid = (out_rows + a.rows_per_block - 1) / a.rows_per_block;
   const size_t lds = (size_t)a.chunks * 1024 * sizeof(float);
   if (lds > 64 * 1024) {
     static bool raised = false;  // per instantiation; the attribute is sticky
     if (!raised) {
-      KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_w8_kernel<R, U, GU>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_w8_kernel<R, U, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
       raised = true;
     }
   }
-  hipLaunchKernelGGL((gemv_w8_kernel<R, U, GU>), dim3(grid), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((gemv_w8_kernel<R, U, MODE>), dim3(grid), dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -225,7 +333,7 @@ static int ilog2(int v) {
   return s;
 }
 
-static int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, hipStream_t s) {
+int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) {
   if (!a.x || !a.w || !a.scales || !a.y0) return KX_EINVAL;
   if (a.M <= 0 || a.K <= 0 || group_size <= 0) return KX_EINVAL;
   if (a.M % 4 != 0) return KX_EINVAL;  // matmul_kernel.cu:123
@@ -233,9 +341,10 @@ static int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, hipStream_t s) {
   const bool pow2 = (group_size & (group_size - 1)) == 0;
   const bool fast = pow2 && group_size % 16 == 0 && a.M % group_size == 0 && a.M % 16 == 0 &&
                     ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&
-                    (size_t)a.M * 4 <= 160 * 1024;
+                    (!a.norm_w || (uintptr_t)a.norm_w % 16 == 0) &&
+                    (size_t)((a.M + 1023) / 1024) * 4096 <= 160 * 1024 - 64;
   if (!fast) {
-    if (a.swiglu_half > 0) return KX_EUNSUPPORTED;
+    if (mode != GEMV_PLAIN || a.norm_w) return KX_EUNSUPPORTED;
     const int wpb = 4;
     hipLaunchKernelGGL(gemv_w8_generic_kernel, dim3((a.K + wpb - 1) / wpb), dim3(wpb * 64), 0, s, a,
                        group_size);
@@ -251,21 +360,27 @@ static int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, hipStream_t s) {
   if (lds > 32 * 1024) threads = 512;
   if (lds > 80 * 1024) threads = 1024;
   const int waves = threads / 64;
-  const int out_rows = a.swiglu_half > 0 ? a.swiglu_half : a.K;
-  const bool fused2 = a.swiglu_half > 0;
+  const int out_rows = mode == GEMV_GATE_UP ? a.swiglu_half : a.K;
   // rows a wave keeps in flight together; the gate/up form already doubles the loads
-  const int R = fused2 ? 1 : (a.chunks <= 2 ? 4 : 2);
+  const int R = mode == GEMV_GATE_UP ? 1 : (a.chunks <= 2 ? 4 : 2);
   const int per_iter = waves * R;
   // aim for ~4 workgroups per CU on big matrices, one pass on small ones
   const int target_blocks = 256 * 4;
   int rpb = (out_rows + target_blocks - 1) / target_blocks;
   rpb = ((rpb + per_iter - 1) / per_iter) * per_iter;
   a.rows_per_block = rpb;
-  if (fused2) {
-    return a.chunks <= 2 ? launch<1, 2, true>(a, threads, s) : launch<1, 4, true>(a, threads, s);
+  switch (mode) {
+    case GEMV_GATE_UP:
+      return a.chunks <= 2 ? launch<1, 2, GEMV_GATE_UP>(a, threads, s)
+                           : launch<1, 4, GEMV_GATE_UP>(a, threads, s);
+    case GEMV_QKV_ROPE:
+      if (a.K % 2 || a.k0 % 2 || a.k1 % 2 || a.head_size % 2) return KX_EINVAL;
+      return a.chunks <= 2 ? launch<4, 2, GEMV_QKV_ROPE>(a, threads, s)
+                           : launch<2, 4, GEMV_QKV_ROPE>(a, threads, s);
+    default:
+      return a.chunks <= 2 ? launch<4, 2, GEMV_PLAIN>(a, threads, s)
+                           : launch<2, 4, GEMV_PLAIN>(a, threads, s);
   }
-  if (a.chunks <= 2) return launch<4, 2, false>(a, threads, s);
-  return launch<2, 4, false>(a, threads, s);
 }
 
 }  // namespace kx
@@ -282,8 +397,7 @@ extern "C" int kx_gemv_w8_f32_ex(const float* x, const int8_t* w, const float* s
   a.k0 = k0; a.k1 = k1;
   a.bias = bias; a.residual = residual;
   a.M = M; a.K = K;
-  a.swiglu_half = 0;
-  return kx::gemv_w8_dispatch(a, group_size, (hipStream_t)stream);
+  return kx::gemv_w8_dispatch(a, group_size, kx::GEMV_PLAIN, (hipStream_t)stream);
 }
 
 extern "C" int kx_gemv_w8_f32(const float* x, const int8_t* w, const float* scales,
@@ -301,5 +415,42 @@ extern "C" int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const fl
   a.k0 = a.k1 = H;
   a.M = M; a.K = 2 * H;
   a.swiglu_half = H;
-  return kx::gemv_w8_dispatch(a, group_size, (hipStream_t)stream);
+  return kx::gemv_w8_dispatch(a, group_size, kx::GEMV_GATE_UP, (hipStream_t)stream);
+}
+
+extern "C" int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* d, void* stream) {
+  if (!d) return KX_EINVAL;
+  kx::GemvW8Args a{};
+  a.x = d->x; a.w = d->w; a.scales = d->scales;
+  a.norm_w = d->norm_w; a.norm_eps = d->norm_eps;
+  a.M = d->M; a.K = d->K;
+  a.bias = d->bias;
+  int32_t k0 = d->k0, k1 = d->k1;
+  a.y0 = d->y0; a.y1 = d->y1 ? d->y1 : d->y0; a.y2 = d->y2 ? d->y2 : d->y0;
+  if (!d->y1 && !d->y2) { k0 = d->K; k1 = d->K; }
+  switch (d->mode) {
+    case KX_GEMV_PLAIN:
+      a.residual = d->residual;
+      break;
+    case KX_GEMV_GATE_UP:
+      if (d->K % 2 || d->residual) return KX_EINVAL;
+      a.swiglu_half = d->K / 2;
+      k0 = k1 = a.swiglu_half;
+      a.y1 = a.y2 = a.y0;
+      break;
+    case KX_GEMV_QKV_ROPE:
+      if (!d->sin_cache || !d->cos_cache || d->head_size <= 0 || d->residual) return KX_EINVAL;
+      if (k0 % d->head_size || (k1 - k0) % d->head_size) return KX_EINVAL;
+      if (!d->pos_dev && d->pos < 0) return KX_EINVAL;
+      a.sin_cache = d->sin_cache; a.cos_cache = d->cos_cache;
+      a.pos_dev = d->pos_dev; a.pos_val = d->pos;
+      a.rope_variant = d->rope_variant; a.head_size = d->head_size;
+      a.kv_pos_stride = d->kv_pos_stride;
+      break;
+    default:
+      return KX_EINVAL;
+  }
+  if (k0 < 0 || k1 < k0 || k1 > d->K) return KX_EINVAL;
+  a.k0 = k0; a.k1 = k1;
+  return kx::gemv_w8_dispatch(a, d->group_size, d->mode, (hipStream_t)stream);
 }

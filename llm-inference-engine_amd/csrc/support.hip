@@ -131,6 +131,23 @@ __global__ void embedding_kernel(const int32_t* __restrict__ tokens, const float
   }
 }
 
+// Same gather for one decode step with everything on the device: the token is history[*pos].
+__global__ void embedding_dpos_kernel(const int32_t* __restrict__ history,
+                                      const int32_t* __restrict__ pos,
+                                      const float* __restrict__ table, float* __restrict__ out,
+                                      int dim, int vocab) {
+  int tok = history[*pos];
+  if (tok < 0 || tok >= vocab) tok = 0;
+  const float* src = table + (size_t)tok * dim;
+  if (dim % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim / 4; i += gridDim.x * blockDim.x)
+      reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(src)[i];
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x)
+      out[i] = src[i];
+  }
+}
+
 // argmax_kernel_fp32 (cuda/argmax_kernel.cu:49-71): first maximum wins.  Single workgroup.
 __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
   if (ov > v || (ov == v && oi < i)) {
@@ -165,6 +182,74 @@ __global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out) 
   if (threadIdx.x == 0) {
     for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
     *out = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
+// Greedy sampling + bookkeeping of one decode step, all on the device so that a captured token
+// graph can be replayed without the host in the loop: next = argmax(logits) (first maximum
+// wins, argmax_sampler.cpp:6-8); history[pos+1] = next; token = next; pos += 1.
+__global__ void decode_step_end_kernel(const float* __restrict__ x, int n, int32_t* token,
+                                       int32_t* pos, int32_t* history, int history_len) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = x[i];
+    if (v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    argmax_merge(best, bi, ov, oi);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) {
+    sv[wave] = best;
+    si[wave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
+    if (bi == 0x7fffffff) bi = 0;
+    const int p = *pos;
+    if (history && p + 1 < history_len) history[p + 1] = bi;
+    *token = bi;
+    *pos = p + 1;
+  }
+}
+
+// ---- seeded synthetic tensors, generated on the device ----
+// Element (i, j) of the GLOBAL matrix gets a value that depends only on (seed, i*ld + j), so a
+// tensor-parallel shard holds exactly the slice of the unsharded tensor.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void fill_hash_i8_kernel(int8_t* dst, int rows, int cols, int64_t ld, int64_t row0,
+                                    int64_t col0, uint64_t seed) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / cols, j = t - i * cols;
+    const uint64_t h = mix64(seed ^ (uint64_t)((row0 + i) * ld + col0 + j) * 0xD1342543DE82EF95ull);
+    dst[t] = (int8_t)((int)(h % 255ull) - 127);
+  }
+}
+__global__ void fill_hash_f32_kernel(float* dst, int rows, int cols, int64_t ld, int64_t row0,
+                                     int64_t col0, uint64_t seed, float lo, float hi) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / cols, j = t - i * cols;
+    const uint64_t h = mix64(seed ^ (uint64_t)((row0 + i) * ld + col0 + j) * 0xD1342543DE82EF95ull);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    dst[t] = lo + (hi - lo) * u;
   }
 }
 
@@ -243,6 +328,44 @@ extern "C" int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index,
   if (!logits || !out_index || n <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n,
                      out_index);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev,
+                                  int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
+                                  void* stream) {
+  if (!logits || !token_dev || !pos_dev || n <= 0) return KX_EINVAL;
+  hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n,
+                     token_dev, pos_dev, history_dev, history_len);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_fill_hash_i8(int8_t* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0,
+                               int64_t col0, uint64_t seed, void* stream) {
+  if (!dst || rows <= 0 || cols <= 0) return KX_EINVAL;
+  hipLaunchKernelGGL(fill_hash_i8_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dst, rows,
+                     cols, ld, row0, col0, seed);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_fill_hash_f32(float* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0,
+                                int64_t col0, uint64_t seed, float lo, float hi, void* stream) {
+  if (!dst || rows <= 0 || cols <= 0) return KX_EINVAL;
+  hipLaunchKernelGGL(fill_hash_f32_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dst, rows,
+                     cols, ld, row0, col0, seed, lo, hi);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_embedding_dpos_f32(const int32_t* history_dev, const int32_t* pos_dev,
+                                     const float* table, int32_t dim, int32_t vocab_size,
+                                     float* out, void* stream) {
+  if (!history_dev || !pos_dev || !table || !out || dim <= 0 || vocab_size <= 0) return KX_EINVAL;
+  hipLaunchKernelGGL(embedding_dpos_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, history_dev,
+                     pos_dev, table, out, dim, vocab_size);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

@@ -1,0 +1,65 @@
+/*
+ * kx_host.h -- C view of the C++17 host layer (libkx_host.so) for FFI callers (the Python tests
+ * and benchmark driver).  The host layer itself is C++: base::, tensor::, op::, kernel::,
+ * model:: under host/include; this header only exposes the model driver.
+ * Every call returns 0 on success; kxm_last_error() describes the last failure.
+ */
+#ifndef KX_HOST_H_
+#define KX_HOST_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kxm_config {
+  int32_t dim, hidden_dim, layer_num, head_num, kv_head_num, vocab_size, seq_len;
+  int32_t group_size;   /* 0 = fp32 weights */
+  int32_t rope_variant; /* 0 interleaved, 1 half split */
+  float rope_theta;
+  float rms_eps;
+  int32_t tp_size, tp_rank;
+} kxm_config;
+
+const char* kxm_last_error(void);
+void* kxm_create(const kxm_config* cfg);
+void kxm_destroy(void* model);
+int kxm_init_synthetic(void* model, uint64_t seed);
+int kxm_load_blob(void* model, const void* blob, size_t bytes);
+int kxm_read_weight(void* model, const char* name, int32_t layer, void* host_out, size_t bytes);
+int kxm_comm_unique_id(void* id128);
+int kxm_init_comm(void* model, const void* id128);
+int kxm_forward_layers(void* model, int32_t token, int32_t pos, float* logits_host);
+int kxm_set_state(void* model, int32_t token, int32_t pos);
+int kxm_step_logits(void* model, int32_t token, int32_t pos, float* logits_host);
+int kxm_decode(void* model, int32_t steps, int32_t use_graph);
+int kxm_prefill(void* model, const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);
+int kxm_read_history(void* model, int32_t* out, int32_t n);
+int kxm_read_state(void* model, int32_t* token, int32_t* pos);
+int kxm_read_kv(void* model, int32_t layer, int32_t rows, float* k_host, float* v_host);
+int kxm_sync(void* model);
+int kxm_profile_gemv(void* model, int32_t steps, int64_t* launches, double* bytes, double* ms);
+double kxm_linear_bytes_per_token(void* model);
+void* kxm_stream(void* model);
+
+/* Layer-level checks used by the tests: run one op::MatmulLayer / op::MultiHeadAttention /
+ * op::FlashAttention forward on DeviceType::kDeviceHIP from host arrays. */
+int kxm_test_matmul_layer(const float* x, const void* w, const float* scales, int32_t group_size,
+                          const float* bias, int32_t dim0, int32_t dim1, int32_t rows, float* y);
+int kxm_test_mha_layer(const float* q, const float* kcache, const float* vcache, int32_t layers,
+                       int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
+                       int32_t layer_idx, int32_t pos, float* out);
+int kxm_test_flash_layer(const float* q, const float* kcache, const float* vcache, int32_t layers,
+                         int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
+                         int32_t layer_idx, int32_t pos, int32_t tq, float* out);
+/* base::KVCacheManager layout probe: byte offsets of (layer) K and V pointers from the K base and
+ * the arena size. */
+int kxm_test_kv_layout(int32_t layers, int32_t seq_len, int32_t kv_head_num, int32_t head_size,
+                       int32_t layer_idx, int64_t* k_off, int64_t* v_off, int64_t* total_bytes);
+/* Registry contract: returns 1 when every getter hands back a kernel for kDeviceHIP. */
+int kxm_test_registry(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

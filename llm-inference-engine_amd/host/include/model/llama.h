@@ -1,0 +1,169 @@
+// Llama-family token loop on the HIP device.
+//
+// Host orchestration of the hot path, re-written rather than mirrored: the reference's
+// LLama2Model (kuiper/source/model/llama3.cpp) hand-unrolls one token per predict() call with
+// one launch per op and reads the position on the host.  Two paths are offered here:
+//
+//   forward_layers()  the reference-structured path: one op::Layer::forward per op, through the
+//                     kernel registry (attention_rms / attention_qkv / attention_mha /
+//                     feed_forward / cls_logits, llama3.cpp:637-799).  This is the drop-in
+//                     surface; it exists so the registry and the layers are exercised end to end.
+//   decode()          the fused path: per layer [RMSNorm+Wq|Wk|Wv+RoPE+KV write] -> attention ->
+//                     [Wo+residual] -> [RMSNorm+W1|W3+SwiGLU] -> [W2+residual]; token id and
+//                     position live on the device, the whole step is captured once in a HIP graph
+//                     and replayed, so the host is out of the loop.
+//   prefill()         T prompt rows at once (MFMA GEMMs + flash attention), new capability; it
+//                     leaves the KV cache and last-row logits that T decode steps would.
+//
+// Tensor parallelism: column-parallel Wq/Wk/Wv/W1/W3, row-parallel Wo/W2 with an all-reduce after
+// each (the hook at kuiper/source/op/matmul.cpp:81-127), one process per GPU.
+#ifndef KX_HOST_MODEL_LLAMA_H_
+#define KX_HOST_MODEL_LLAMA_H_
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "base/kv_cache_manager.h"
+#include "base/rccl_handler.h"
+#include "op/flash_attention.h"
+#include "op/matmul.h"
+#include "op/mha.h"
+#include "op/support_layers.h"
+
+namespace model {
+
+// Header of the exporter's files: 7 x int32 (+ group_size for quant files).
+// kuiper/include/model/config.h:4-15, tools/export_llama.py:91-93,148-150.
+struct ModelConfig {
+  int32_t dim = 0;
+  int32_t hidden_dim = 0;
+  int32_t layer_num = 0;
+  int32_t head_num = 0;
+  int32_t kv_head_num = 0;
+  int32_t vocab_size = 0;
+  int32_t seq_len = 0;
+};
+
+struct TransformerConfig {
+  int32_t dim = 0, hidden_dim = 0, layer_num = 0, head_num = 0, kv_head_num = 0;
+  int32_t vocab_size = 0, seq_len = 0;
+  int32_t group_size = 0;    // 0 = fp32 weights
+  int32_t rope_variant = 0;  // KX_ROPE_*; the reference's LLAMA3/QWEN2 compile-time switch
+  float rope_theta = 10000.f;
+  float rms_eps = 1e-5f;
+  int32_t tp_size = 1, tp_rank = 0;
+  // derived (model.cpp:132-134)
+  int32_t kv_dim = 0, kv_mul = 0, head_size = 0;
+  // per-rank sizes under tensor parallelism
+  int32_t q_dim_local = 0, kv_dim_local = 0, hidden_local = 0, head_local = 0, kv_head_local = 0;
+  base::Status finalize();
+};
+
+class LlamaModel {
+ public:
+  LlamaModel();
+  ~LlamaModel();
+  LlamaModel(const LlamaModel&) = delete;
+  LlamaModel& operator=(const LlamaModel&) = delete;
+
+  // Allocates weights, activation buffers, RoPE tables and the KV cache on the current device.
+  base::Status init(const TransformerConfig& cfg);
+
+  // ---- weights ----
+  // Seeded random weights generated on the device: int8 uniform in [-127,127] with scales
+  // U(1e-4, 3e-4) (or fp32 U(-0.035,0.035) for group_size 0), fp32 embedding, norm weights 1.
+  base::Status init_synthetic(uint64_t seed);
+  // The exporter's byte layouts: legacy fp32 (tools/export_llama.py:79-131) or quant
+  // (:134-210), chosen by cfg.group_size; reader logic of model.cpp:52-122, llama3.cpp:201-440.
+  // Tensor-parallel ranks take their shard of every matrix.
+  base::Status load_blob(const void* blob, size_t bytes);
+  // Host copy of one weight as stored on this rank.  name: wq wk wv wo w1 w2 w3 cls (int8 or fp32
+  // data), *_s (scales), emb, attn_norm, ffn_norm, final_norm.
+  base::Status read_weight(const std::string& name, int32_t layer, void* host_out, size_t bytes) const;
+
+  base::Status init_comm(const base::CommUniqueId* id);
+
+  // ---- reference-structured path ----
+  base::Status forward_layers(int32_t token, int32_t pos, float* logits_host);
+
+  // ---- fused path ----
+  base::Status set_state(int32_t token, int32_t pos);          // device token id + position
+  base::Status step_logits(int32_t token, int32_t pos, float* logits_host);  // one fused step
+  base::Status decode(int32_t steps, bool use_graph);           // greedy, host out of the loop
+  base::Status read_history(int32_t* out, int32_t n) const;     // token at each position
+  base::Status read_state(int32_t* token, int32_t* pos) const;
+  base::Status prefill(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);
+
+  base::Status read_kv(int32_t layer, int32_t rows, float* k_host, float* v_host) const;
+  base::Status sync() const;
+
+  // Per-launch timing of the W8 GEMV entries inside one fused step (HIP events on the compute
+  // stream): returns launches, summed algorithmic bytes and summed milliseconds.
+  base::Status profile_gemv(int32_t steps, int64_t* launches, double* bytes, double* ms);
+
+  const TransformerConfig& config() const { return cfg_; }
+  std::shared_ptr<kernel::CudaConfig> hip_config() const { return hip_; }
+  double linear_weight_bytes_per_token() const;  // algorithmic bytes of all GEMVs of one step
+
+ private:
+  struct Linear {  // one (possibly stacked) matrix per layer on the device
+    void* w = nullptr;       // int8 or fp32 [rows][cols]
+    float* s = nullptr;      // scales (quant only)
+    float* bias = nullptr;   // optional fp32 [rows]
+    int32_t rows = 0, cols = 0;
+    size_t w_bytes() const;
+  };
+  struct LayerWeights {
+    Linear qkv, wo, w13, w2;
+    float* attn_norm = nullptr;
+    float* ffn_norm = nullptr;
+  };
+
+  base::Status alloc_linear(Linear& l, int32_t rows, int32_t cols);
+  void free_linear(Linear& l);
+  base::Status fill_linear_rows(Linear& l, int32_t row_off, int32_t rows, int64_t g_ld,
+                                int64_t g_row0, int64_t g_col0, uint64_t seed);
+  base::Status upload_matrix(Linear& l, int32_t dst_row_off, const void* src_w, const float* src_s,
+                             int32_t g_rows, int32_t g_cols, int32_t row0, int32_t rows,
+                             int32_t col0, int32_t cols);
+  void build_layers();
+  base::Status launch_step(void* stream, bool with_events);
+  base::Status gemv(const Linear& l, int mode, const float* x, const float* norm_w, float* y0,
+                    float* y1, float* y2, int32_t k0, int32_t k1, const float* residual,
+                    void* stream);
+  base::Status all_reduce(float* buf, size_t count);
+
+  TransformerConfig cfg_;
+  bool quant_ = false;
+  std::shared_ptr<kernel::CudaConfig> hip_;
+  std::vector<LayerWeights> layers_;
+  Linear cls_;
+  float* emb_ = nullptr;
+  float* final_norm_ = nullptr;
+  std::unique_ptr<base::KVCacheManager> kv_;
+
+  // activations (device)
+  float *x_ = nullptr, *q_ = nullptr, *att_ = nullptr, *h_ = nullptr, *logits_ = nullptr;
+  float *rms_ = nullptr, *h3_ = nullptr, *tmp_dim_ = nullptr;  // layer-path scratch
+  float *sin_ = nullptr, *cos_ = nullptr;
+  int32_t *token_dev_ = nullptr, *pos_dev_ = nullptr, *history_dev_ = nullptr;
+  // prefill scratch, grown on demand
+  float* pf_ = nullptr;
+  size_t pf_bytes_ = 0;
+
+  void* graph_ = nullptr;
+
+  // reference-structured path
+  struct RefLayers;
+  std::unique_ptr<RefLayers> ref_;
+
+  // profiling
+  bool prof_on_ = false;
+  std::vector<std::pair<void*, void*>> prof_events_;
+  std::vector<double> prof_bytes_;
+  size_t prof_cursor_ = 0;
+};
+
+}  // namespace model
+#endif

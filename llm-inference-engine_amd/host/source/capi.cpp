@@ -1,0 +1,198 @@
+// extern "C" shim over model::LlamaModel and a few layer-level probes (host/include/kx_host.h).
+#include "kx_host.h"
+
+#include <cstring>
+#include <string>
+
+#include "kx_hip.h"
+#include "model/llama.h"
+#include "op/kernels/kernels_interface.h"
+
+namespace {
+thread_local std::string g_err;
+int fail(const base::Status& s) {
+  g_err = s.get_err_msg();
+  if (g_err.empty()) g_err = "status code " + std::to_string(int(s));
+  return int(s) ? int(s) : -1;
+}
+int done(const base::Status& s) { return s ? 0 : fail(s); }
+model::LlamaModel* M(void* p) { return static_cast<model::LlamaModel*>(p); }
+constexpr base::DeviceType kHip = base::DeviceType::kDeviceHIP;
+
+tensor::Tensor dev_from_host(base::DataType dt, std::vector<int32_t> dims, const void* host) {
+  tensor::Tensor t(dt, std::move(dims), true, base::HIPDeviceAllocatorFactory::get_instance());
+  if (host && t.byte_size()) kx_memcpy_h2d(t.ptr<void>(), host, t.byte_size(), nullptr);
+  return t;
+}
+}  // namespace
+
+extern "C" {
+const char* kxm_last_error(void) { return g_err.c_str(); }
+
+void* kxm_create(const kxm_config* c) {
+  if (!c) return nullptr;
+  model::TransformerConfig t;
+  t.dim = c->dim; t.hidden_dim = c->hidden_dim; t.layer_num = c->layer_num;
+  t.head_num = c->head_num; t.kv_head_num = c->kv_head_num; t.vocab_size = c->vocab_size;
+  t.seq_len = c->seq_len; t.group_size = c->group_size; t.rope_variant = c->rope_variant;
+  t.rope_theta = c->rope_theta; t.rms_eps = c->rms_eps;
+  t.tp_size = c->tp_size < 1 ? 1 : c->tp_size; t.tp_rank = c->tp_rank;
+  auto* m = new model::LlamaModel();
+  base::Status s = m->init(t);
+  if (!s) {
+    fail(s);
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+void kxm_destroy(void* m) { delete M(m); }
+int kxm_init_synthetic(void* m, uint64_t seed) { return done(M(m)->init_synthetic(seed)); }
+int kxm_load_blob(void* m, const void* blob, size_t bytes) { return done(M(m)->load_blob(blob, bytes)); }
+int kxm_read_weight(void* m, const char* name, int32_t layer, void* out, size_t bytes) {
+  return done(M(m)->read_weight(name, layer, out, bytes));
+}
+int kxm_comm_unique_id(void* id128) {
+  base::CommUniqueId id;
+  base::Status s = base::RcclHandler::CreateUniqueId(&id);
+  if (!s) return fail(s);
+  std::memcpy(id128, id.data(), id.size());
+  return 0;
+}
+int kxm_init_comm(void* m, const void* id128) {
+  base::CommUniqueId id;
+  if (id128) std::memcpy(id.data(), id128, id.size());
+  return done(M(m)->init_comm(id128 ? &id : nullptr));
+}
+int kxm_forward_layers(void* m, int32_t token, int32_t pos, float* logits) {
+  return done(M(m)->forward_layers(token, pos, logits));
+}
+int kxm_set_state(void* m, int32_t token, int32_t pos) { return done(M(m)->set_state(token, pos)); }
+int kxm_step_logits(void* m, int32_t token, int32_t pos, float* logits) {
+  return done(M(m)->step_logits(token, pos, logits));
+}
+int kxm_decode(void* m, int32_t steps, int32_t use_graph) { return done(M(m)->decode(steps, use_graph != 0)); }
+int kxm_prefill(void* m, const int32_t* tokens, int32_t n, int32_t pos0, float* logits) {
+  return done(M(m)->prefill(tokens, n, pos0, logits));
+}
+int kxm_read_history(void* m, int32_t* out, int32_t n) { return done(M(m)->read_history(out, n)); }
+int kxm_read_state(void* m, int32_t* token, int32_t* pos) { return done(M(m)->read_state(token, pos)); }
+int kxm_read_kv(void* m, int32_t layer, int32_t rows, float* k, float* v) {
+  return done(M(m)->read_kv(layer, rows, k, v));
+}
+int kxm_sync(void* m) { return done(M(m)->sync()); }
+int kxm_profile_gemv(void* m, int32_t steps, int64_t* launches, double* bytes, double* ms) {
+  return done(M(m)->profile_gemv(steps, launches, bytes, ms));
+}
+double kxm_linear_bytes_per_token(void* m) { return M(m)->linear_weight_bytes_per_token(); }
+void* kxm_stream(void* m) { return M(m)->hip_config()->stream; }
+
+// ---------------- layer-level probes ----------------
+int kxm_test_matmul_layer(const float* x, const void* w, const float* scales, int32_t group_size,
+                          const float* bias, int32_t dim0, int32_t dim1, int32_t rows, float* y) {
+  auto cfg = std::make_shared<kernel::CudaConfig>();
+  if (int rc = cfg->create_streams()) return rc;
+  const bool quant = group_size > 0;
+  op::MatmulLayer layer(kHip, dim0, dim1, quant, bias != nullptr);
+  layer.set_cuda_config(cfg);
+  // Bind host memory exactly as the reference's loaders do (weights then scales in one blob for
+  // quant layers, layer.cpp:203-216), then move the layer to the device.
+  std::vector<uint8_t> blob;
+  if (quant) {
+    const size_t n = (size_t)dim0 * dim1;
+    blob.resize(n + (n / group_size) * 4);
+    std::memcpy(blob.data(), w, n);
+    std::memcpy(blob.data() + n, scales, (n / group_size) * 4);
+    layer.set_group_size(group_size);
+    layer.set_weight(0, {dim0, dim1}, blob.data(), base::DeviceType::kDeviceCPU);
+  } else {
+    layer.set_weight(0, {dim0, dim1}, w, base::DeviceType::kDeviceCPU);
+  }
+  int32_t bdim = dim0;
+  if (bias) layer.set_bias(0, bdim, bias, base::DeviceType::kDeviceCPU);
+  layer.to_cuda();
+  tensor::Tensor in = rows > 1 ? dev_from_host(base::DataType::kDataTypeFp32, {rows, dim1}, x)
+                               : dev_from_host(base::DataType::kDataTypeFp32, {dim1}, x);
+  tensor::Tensor out = rows > 1 ? dev_from_host(base::DataType::kDataTypeFp32, {rows, dim0}, nullptr)
+                                : dev_from_host(base::DataType::kDataTypeFp32, {dim0}, nullptr);
+  base::Status s = layer.forward(in, out);
+  if (!s) return fail(s);
+  kx_stream_sync(cfg->stream);
+  out.to_cpu();
+  std::memcpy(y, out.ptr<float>(), out.byte_size());
+  return 0;
+}
+
+static int attn_common(bool flash, const float* q, const float* kc, const float* vc, int32_t layers,
+                       int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
+                       int32_t layer_idx, int32_t pos, int32_t tq, float* out_host) {
+  auto cfg = std::make_shared<kernel::CudaConfig>();
+  if (int rc = cfg->create_streams()) return rc;
+  if (int rc = cfg->reserve_attn_workspace(head_num, head_size, seq_len)) return rc;
+  const int32_t kv_dim = head_num / kv_mul * head_size;
+  const base::DataType f32 = base::DataType::kDataTypeFp32;
+  tensor::Tensor key = dev_from_host(f32, {layers, seq_len, kv_dim}, kc);
+  tensor::Tensor val = dev_from_host(f32, {layers, seq_len, kv_dim}, vc);
+  tensor::Tensor query = dev_from_host(f32, {tq, head_num * head_size}, q);
+  tensor::Tensor out = dev_from_host(f32, {tq, head_num * head_size}, nullptr);
+  base::Status s;
+  if (flash) {
+    op::FlashAttention layer(kHip, 0, kv_mul, kv_dim, seq_len, head_num, head_size);
+    layer.set_cuda_config(cfg);
+    layer.set_pos(pos);
+    layer.set_layer_idx(layer_idx);
+    s = layer.forward(query, key, val, out);
+  } else {
+    op::MultiHeadAttention layer(kHip, 0, kv_mul, kv_dim, seq_len, head_num, head_size);
+    layer.set_cuda_config(cfg);
+    layer.set_pos(pos);
+    layer.set_layer_idx(layer_idx);
+    tensor::Tensor score = dev_from_host(f32, {head_num, seq_len}, nullptr);
+    s = layer.forward(query, score, key, val, out);
+  }
+  if (!s) return fail(s);
+  kx_stream_sync(cfg->stream);
+  out.to_cpu();
+  std::memcpy(out_host, out.ptr<float>(), out.byte_size());
+  return 0;
+}
+
+int kxm_test_mha_layer(const float* q, const float* kc, const float* vc, int32_t layers,
+                       int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
+                       int32_t layer_idx, int32_t pos, float* out) {
+  return attn_common(false, q, kc, vc, layers, seq_len, head_num, kv_mul, head_size, layer_idx, pos,
+                     1, out);
+}
+int kxm_test_flash_layer(const float* q, const float* kc, const float* vc, int32_t layers,
+                         int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
+                         int32_t layer_idx, int32_t pos, int32_t tq, float* out) {
+  return attn_common(true, q, kc, vc, layers, seq_len, head_num, kv_mul, head_size, layer_idx, pos,
+                     tq, out);
+}
+
+int kxm_test_kv_layout(int32_t layers, int32_t seq_len, int32_t kv_head_num, int32_t head_size,
+                       int32_t layer_idx, int64_t* k_off, int64_t* v_off, int64_t* total_bytes) {
+  base::KVCacheConfig c;
+  c.max_seq_len = seq_len;
+  c.layer_num = layers;
+  c.kv_head_num = kv_head_num;
+  c.kv_dim = kv_head_num * head_size;
+  base::KVCacheManager mgr(base::DeviceType::kDeviceCPU, c);  // host arena: layout only
+  base::Status s = mgr.allocate();
+  if (!s) return fail(s);
+  auto [k, v] = mgr.get_cache_ptr(layer_idx);
+  const char* base_ptr = static_cast<const char*>(mgr.get_raw_buffer_k());
+  *k_off = static_cast<const char*>(k) - base_ptr;
+  *v_off = static_cast<const char*>(v) - base_ptr;
+  *total_bytes = static_cast<int64_t>(mgr.total_bytes());
+  return 0;
+}
+
+int kxm_test_registry(void) {
+  using namespace kernel;
+  return get_add_kernel(kHip) && get_emb_kernel(kHip) && get_matmul_kernel(kHip) &&
+         get_matmul_kernel_quant8(kHip) && get_mha_kernel(kHip) && get_rmsnorm_kernel(kHip) &&
+         get_rmsnorm_dim_kernel(kHip) && get_rope_kernel(kHip) && get_swiglu_kernel(kHip) &&
+         get_flash_attention_kernel(kHip);
+}
+}  // extern "C"

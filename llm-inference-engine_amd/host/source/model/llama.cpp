@@ -1,0 +1,795 @@
+#include "model/llama.h"
+
+#include <cstring>
+
+#include "kx_hip.h"
+#include "op/kernels/kernels_interface.h"
+
+namespace model {
+namespace {
+constexpr base::DeviceType kHip = base::DeviceType::kDeviceHIP;
+
+base::Status rc_status(int rc, const char* what) {
+  if (rc == 0) return base::error::Success();
+  return base::error::InternalError(std::string(what) + ": " + kx_error_string(rc) + " (rc " +
+                                    std::to_string(rc) + ")");
+}
+#define KX_RET(expr)                                  \
+  do {                                                \
+    base::Status st_ = rc_status((expr), #expr);      \
+    if (!st_) return st_;                             \
+  } while (0)
+#define ST_RET(expr)            \
+  do {                          \
+    base::Status st_ = (expr);  \
+    if (!st_) return st_;       \
+  } while (0)
+
+template <typename T>
+base::Status dev_alloc(T*& p, size_t count) {
+  void* v = nullptr;
+  int rc = kx_malloc(&v, count * sizeof(T));
+  if (rc) return rc_status(rc, "kx_malloc");
+  rc = kx_memset(v, 0, count * sizeof(T), nullptr);
+  p = static_cast<T*>(v);
+  return rc_status(rc, "kx_memset");
+}
+template <typename T>
+void dev_free(T*& p) {
+  if (p) kx_free(p);
+  p = nullptr;
+}
+
+tensor::Tensor view(base::DataType dt, std::vector<int32_t> dims, void* ptr) {
+  tensor::Tensor t(dt, std::move(dims), false, nullptr, ptr);
+  t.set_device_type(kHip);
+  return t;
+}
+
+double gemv_bytes(int64_t K, int64_t M, int gs) {
+  return (double)K * M + 4.0 * (double)K * M / gs + 4.0 * (double)(M + K);
+}
+}  // namespace
+
+base::Status TransformerConfig::finalize() {
+  if (dim <= 0 || hidden_dim <= 0 || layer_num <= 0 || head_num <= 0 || kv_head_num <= 0 ||
+      vocab_size <= 0 || seq_len <= 0)
+    return base::error::InvalidArgument("model config has a non-positive dimension");
+  if (dim % head_num || head_num % kv_head_num)
+    return base::error::InvalidArgument("dim/head_num/kv_head_num do not divide");
+  head_size = dim / head_num;                 // model.cpp:134
+  kv_dim = (dim * kv_head_num) / head_num;    // model.cpp:132
+  kv_mul = head_num / kv_head_num;            // model.cpp:133
+  if (tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size)
+    return base::error::InvalidArgument("bad tensor-parallel rank/size");
+  if (head_num % tp_size || kv_head_num % tp_size || hidden_dim % tp_size)
+    return base::error::InvalidArgument("heads / kv heads / hidden_dim must divide by tp_size");
+  head_local = head_num / tp_size;
+  kv_head_local = kv_head_num / tp_size;
+  q_dim_local = head_local * head_size;
+  kv_dim_local = kv_head_local * head_size;
+  hidden_local = hidden_dim / tp_size;
+  if (group_size > 0) {
+    // quant groups run along the input dimension; row-parallel shards must cut on group borders
+    if (dim % group_size || hidden_dim % group_size || q_dim_local % group_size ||
+        hidden_local % group_size)
+      return base::error::InvalidArgument("dims (and tensor-parallel shards) must be multiples of group_size");
+  }
+  return base::error::Success();
+}
+
+size_t LlamaModel::Linear::w_bytes() const { return (size_t)rows * cols; }
+
+// ------------------------------------------------------------------------------------------
+struct LlamaModel::RefLayers {
+  std::vector<std::shared_ptr<op::MatmulLayer>> wq, wk, wv, wo, w1, w2, w3;
+  std::shared_ptr<op::MatmulLayer> cls;
+  std::vector<std::shared_ptr<op::RmsNormLayer>> rmsnorm;  // attn[L], ffn[L], final
+  std::shared_ptr<op::RoPELayer> rope;
+  std::shared_ptr<op::MultiHeadAttention> mha;
+  std::shared_ptr<op::VecAddLayer> add;
+  std::shared_ptr<op::SwiGLULayer> swiglu;
+  std::shared_ptr<op::EmbeddingLayer> embedding;
+  std::map<ModelBufferType, tensor::Tensor> buffers;
+  tensor::Tensor pos_tensor, token_tensor, token_num;
+};
+
+LlamaModel::LlamaModel() = default;
+
+LlamaModel::~LlamaModel() {
+  if (graph_) kx_graph_destroy(graph_);
+  for (auto& pr : prof_events_) {
+    kx_event_destroy(pr.first);
+    kx_event_destroy(pr.second);
+  }
+  for (auto& l : layers_) {
+    free_linear(l.qkv);
+    free_linear(l.wo);
+    free_linear(l.w13);
+    free_linear(l.w2);
+    dev_free(l.attn_norm);
+    dev_free(l.ffn_norm);
+  }
+  free_linear(cls_);
+  dev_free(emb_); dev_free(final_norm_);
+  dev_free(x_); dev_free(q_); dev_free(att_); dev_free(h_); dev_free(logits_);
+  dev_free(rms_); dev_free(h3_); dev_free(tmp_dim_);
+  dev_free(sin_); dev_free(cos_);
+  dev_free(token_dev_); dev_free(pos_dev_); dev_free(history_dev_);
+  dev_free(pf_);
+}
+
+base::Status LlamaModel::alloc_linear(Linear& l, int32_t rows, int32_t cols) {
+  l.rows = rows;
+  l.cols = cols;
+  const size_t n = (size_t)rows * cols;
+  void* w = nullptr;
+  KX_RET(kx_malloc(&w, quant_ ? n : n * sizeof(float)));
+  l.w = w;
+  if (quant_) ST_RET(dev_alloc(l.s, n / cfg_.group_size));
+  return base::error::Success();
+}
+
+void LlamaModel::free_linear(Linear& l) {
+  if (l.w) kx_free(l.w);
+  l.w = nullptr;
+  dev_free(l.s);
+  dev_free(l.bias);
+}
+
+base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
+  cfg_ = cfg_in;
+  ST_RET(cfg_.finalize());
+  quant_ = cfg_.group_size > 0;
+  hip_ = std::make_shared<kernel::CudaConfig>();
+  KX_RET(hip_->create_streams());  // llama3.cpp:124-128
+  KX_RET(hip_->reserve_attn_workspace(cfg_.head_local, cfg_.head_size, cfg_.seq_len));
+  kernel::model_knobs().rope_variant = cfg_.rope_variant;
+  kernel::model_knobs().rms_eps = cfg_.rms_eps;
+
+  const int32_t dim = cfg_.dim;
+  layers_.resize(cfg_.layer_num);
+  for (auto& l : layers_) {
+    ST_RET(alloc_linear(l.qkv, cfg_.q_dim_local + 2 * cfg_.kv_dim_local, dim));
+    ST_RET(alloc_linear(l.wo, dim, cfg_.q_dim_local));
+    ST_RET(alloc_linear(l.w13, 2 * cfg_.hidden_local, dim));
+    ST_RET(alloc_linear(l.w2, dim, cfg_.hidden_local));
+    ST_RET(dev_alloc(l.attn_norm, dim));
+    ST_RET(dev_alloc(l.ffn_norm, dim));
+  }
+  ST_RET(alloc_linear(cls_, cfg_.vocab_size, dim));
+  ST_RET(dev_alloc(emb_, (size_t)cfg_.vocab_size * dim));
+  ST_RET(dev_alloc(final_norm_, dim));
+
+  ST_RET(dev_alloc(x_, dim));
+  ST_RET(dev_alloc(q_, cfg_.q_dim_local));
+  ST_RET(dev_alloc(att_, cfg_.q_dim_local));
+  ST_RET(dev_alloc(h_, cfg_.hidden_local));
+  ST_RET(dev_alloc(h3_, cfg_.hidden_local));
+  ST_RET(dev_alloc(rms_, dim));
+  ST_RET(dev_alloc(tmp_dim_, dim));
+  ST_RET(dev_alloc(logits_, cfg_.vocab_size));
+  ST_RET(dev_alloc(sin_, (size_t)cfg_.seq_len * cfg_.head_size));
+  ST_RET(dev_alloc(cos_, (size_t)cfg_.seq_len * cfg_.head_size));
+  ST_RET(dev_alloc(token_dev_, 1));
+  ST_RET(dev_alloc(pos_dev_, 1));
+  ST_RET(dev_alloc(history_dev_, cfg_.seq_len + 1));
+  KX_RET(kx_sin_cos_cache_f32(cfg_.head_size, cfg_.seq_len, cfg_.rope_theta, sin_, cos_,
+                              hip_->stream));
+
+  // KV cache: K block then V block, each [layer][seq_len][kv_dim_local] (llama3.cpp:487-496)
+  base::KVCacheConfig kvc;
+  kvc.max_batch_size = 1;
+  kvc.max_seq_len = cfg_.seq_len;
+  kvc.layer_num = cfg_.layer_num;
+  kvc.kv_head_num = cfg_.kv_head_local;
+  kvc.kv_dim = cfg_.kv_dim_local;
+  kv_ = std::make_unique<base::KVCacheManager>(kHip, kvc);
+  ST_RET(kv_->allocate());
+  KX_RET(kx_stream_sync(hip_->stream));
+  build_layers();
+  return base::error::Success();
+}
+
+// ---------------- weights ----------------
+base::Status LlamaModel::fill_linear_rows(Linear& l, int32_t row_off, int32_t rows, int64_t g_ld,
+                                          int64_t g_row0, int64_t g_col0, uint64_t seed) {
+  void* st = hip_->stream;
+  if (quant_) {
+    int8_t* w = static_cast<int8_t*>(l.w) + (size_t)row_off * l.cols;
+    KX_RET(kx_fill_hash_i8(w, rows, l.cols, g_ld, g_row0, g_col0, seed, st));
+    const int gs = cfg_.group_size;
+    float* s = l.s + (size_t)row_off * (l.cols / gs);
+    KX_RET(kx_fill_hash_f32(s, rows, l.cols / gs, g_ld / gs, g_row0, g_col0 / gs, seed ^ 0x5ca1e5ull,
+                            1e-4f, 3e-4f, st));
+  } else {
+    float* w = static_cast<float*>(l.w) + (size_t)row_off * l.cols;
+    KX_RET(kx_fill_hash_f32(w, rows, l.cols, g_ld, g_row0, g_col0, seed, -0.035f, 0.035f, st));
+  }
+  return base::error::Success();
+}
+
+base::Status LlamaModel::init_synthetic(uint64_t seed) {
+  const TransformerConfig& c = cfg_;
+  const int r = c.tp_rank;
+  void* st = hip_->stream;
+  std::vector<float> ones(c.dim, 1.0f);
+  for (int l = 0; l < c.layer_num; ++l) {
+    LayerWeights& lw = layers_[l];
+    auto sd = [&](int m) { return seed * 1000003ull + (uint64_t)l * 64 + m; };
+    // column-parallel: this rank's rows of the global matrices
+    ST_RET(fill_linear_rows(lw.qkv, 0, c.q_dim_local, c.dim, (int64_t)r * c.q_dim_local, 0, sd(0)));
+    ST_RET(fill_linear_rows(lw.qkv, c.q_dim_local, c.kv_dim_local, c.dim,
+                            (int64_t)r * c.kv_dim_local, 0, sd(1)));
+    ST_RET(fill_linear_rows(lw.qkv, c.q_dim_local + c.kv_dim_local, c.kv_dim_local, c.dim,
+                            (int64_t)r * c.kv_dim_local, 0, sd(2)));
+    // row-parallel: this rank's columns
+    ST_RET(fill_linear_rows(lw.wo, 0, c.dim, c.dim, 0, (int64_t)r * c.q_dim_local, sd(3)));
+    ST_RET(fill_linear_rows(lw.w13, 0, c.hidden_local, c.dim, (int64_t)r * c.hidden_local, 0, sd(4)));
+    ST_RET(fill_linear_rows(lw.w13, c.hidden_local, c.hidden_local, c.dim,
+                            (int64_t)r * c.hidden_local, 0, sd(6)));
+    ST_RET(fill_linear_rows(lw.w2, 0, c.dim, c.hidden_dim, 0, (int64_t)r * c.hidden_local, sd(5)));
+    KX_RET(kx_memcpy_h2d(lw.attn_norm, ones.data(), c.dim * sizeof(float), nullptr));
+    KX_RET(kx_memcpy_h2d(lw.ffn_norm, ones.data(), c.dim * sizeof(float), nullptr));
+  }
+  ST_RET(fill_linear_rows(cls_, 0, c.vocab_size, c.dim, 0, 0, seed * 1000003ull + 7777));
+  KX_RET(kx_fill_hash_f32(emb_, c.vocab_size, c.dim, c.dim, 0, 0, seed * 1000003ull + 8888, -1.0f,
+                          1.0f, st));
+  KX_RET(kx_memcpy_h2d(final_norm_, ones.data(), c.dim * sizeof(float), nullptr));
+  KX_RET(kx_stream_sync(st));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::upload_matrix(Linear& l, int32_t dst_row_off, const void* src_w,
+                                       const float* src_s, int32_t g_rows, int32_t g_cols,
+                                       int32_t row0, int32_t rows, int32_t col0, int32_t cols) {
+  UNUSED(g_rows);
+  CHECK_EQ(cols, l.cols);
+  const size_t esz = quant_ ? 1 : sizeof(float);
+  std::vector<uint8_t> stage((size_t)rows * cols * esz);
+  const uint8_t* src = static_cast<const uint8_t*>(src_w);
+  for (int32_t i = 0; i < rows; ++i)
+    std::memcpy(stage.data() + (size_t)i * cols * esz,
+                src + ((size_t)(row0 + i) * g_cols + col0) * esz, (size_t)cols * esz);
+  KX_RET(kx_memcpy_h2d(static_cast<uint8_t*>(l.w) + (size_t)dst_row_off * cols * esz, stage.data(),
+                       stage.size(), nullptr));
+  if (quant_) {
+    const int gs = cfg_.group_size;
+    const int32_t gpr = g_cols / gs, lg = cols / gs;
+    std::vector<float> ss((size_t)rows * lg);
+    for (int32_t i = 0; i < rows; ++i)
+      // scales may be unaligned inside the blob: byte copy
+      std::memcpy(ss.data() + (size_t)i * lg,
+                  reinterpret_cast<const uint8_t*>(src_s) +
+                      ((size_t)(row0 + i) * gpr + col0 / gs) * sizeof(float),
+                  (size_t)lg * sizeof(float));
+    KX_RET(kx_memcpy_h2d(l.s + (size_t)dst_row_off * lg, ss.data(), ss.size() * sizeof(float),
+                         nullptr));
+  }
+  return base::error::Success();
+}
+
+base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
+  const TransformerConfig& c = cfg_;
+  const size_t hdr = quant_ ? 32 : 28;  // model.cpp:110-114
+  if (bytes < hdr) return base::error::ModelParseError("blob shorter than its header");
+  ModelConfig mc;
+  std::memcpy(&mc, blob, sizeof(mc));
+  const bool shared = mc.vocab_size > 0;  // model.cpp:138-142
+  if (mc.dim != c.dim || mc.hidden_dim != c.hidden_dim || mc.layer_num != c.layer_num ||
+      mc.head_num != c.head_num || mc.kv_head_num != c.kv_head_num ||
+      std::abs(mc.vocab_size) != c.vocab_size || mc.seq_len > c.seq_len)
+    return base::error::ModelParseError("blob header does not match the model config");
+  if (quant_) {
+    int32_t gs = 0;
+    std::memcpy(&gs, static_cast<const uint8_t*>(blob) + 28, 4);
+    if (gs != c.group_size) return base::error::ModelParseError("group size mismatch");
+    // A tied classifier has no int8 copy in the file (tools/export_llama.py:183-188); the
+    // reference then reads fp32 bytes as int8 (llama3.cpp:276-279).  Refuse instead.
+    if (shared) return base::error::ModelParseError("quant file with tied classifier has no int8 classifier");
+  }
+  const size_t dim = c.dim, hid = c.hidden_dim, L = c.layer_num, V = c.vocab_size;
+  const size_t kvd = c.kv_dim;
+  const int r = c.tp_rank;
+  const uint8_t* p = static_cast<const uint8_t*>(blob) + hdr;
+  const uint8_t* end = static_cast<const uint8_t*>(blob) + bytes;
+  const size_t esz = quant_ ? 1 : 4;
+  auto msize = [&](size_t rows, size_t cols) {
+    const size_t n = rows * cols;
+    return n * esz + (quant_ ? (n / c.group_size) * 4 : 0);
+  };
+  // one matrix kind for all layers, then the next kind (llama3.cpp:210-271, 323-380)
+  auto take = [&](size_t rows, size_t cols, size_t l, const uint8_t*& w, const float*& s) {
+    const uint8_t* base = p + l * msize(rows, cols);
+    w = base;
+    s = reinterpret_cast<const float*>(base + rows * cols * esz);
+  };
+  auto upload_kind = [&](size_t rows, size_t cols, auto&& per_layer) -> base::Status {
+    if (p + L * msize(rows, cols) > end) return base::error::ModelParseError("blob truncated");
+    for (size_t l = 0; l < L; ++l) {
+      const uint8_t* w;
+      const float* s;
+      take(rows, cols, l, w, s);
+      ST_RET(per_layer(l, w, s));
+    }
+    p += L * msize(rows, cols);
+    return base::error::Success();
+  };
+  const float *emb = nullptr, *attn_norm = nullptr, *ffn_norm = nullptr, *final_norm = nullptr;
+  const uint8_t* cls_w = nullptr;
+  const float* cls_s = nullptr;
+  const int32_t ql = c.q_dim_local, kl = c.kv_dim_local, hl = c.hidden_local;
+  auto up_q = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].qkv, 0, w, s, dim, dim, r * ql, ql, 0, dim);
+  };
+  auto up_k = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].qkv, ql, w, s, kvd, dim, r * kl, kl, 0, dim);
+  };
+  auto up_v = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].qkv, ql + kl, w, s, kvd, dim, r * kl, kl, 0, dim);
+  };
+  auto up_o = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].wo, 0, w, s, dim, dim, 0, dim, r * ql, ql);
+  };
+  auto up_1 = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].w13, 0, w, s, hid, dim, r * hl, hl, 0, dim);
+  };
+  auto up_2 = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].w2, 0, w, s, dim, hid, 0, dim, r * hl, hl);
+  };
+  auto up_3 = [&](size_t l, const uint8_t* w, const float* s) {
+    return upload_matrix(layers_[l].w13, hl, w, s, hid, dim, r * hl, hl, 0, dim);
+  };
+  if (!quant_) {
+    // tools/export_llama.py:96-127
+    emb = reinterpret_cast<const float*>(p);        p += V * dim * 4;
+    attn_norm = reinterpret_cast<const float*>(p);  p += L * dim * 4;
+    ST_RET(upload_kind(dim, dim, up_q));
+    ST_RET(upload_kind(kvd, dim, up_k));
+    ST_RET(upload_kind(kvd, dim, up_v));
+    ST_RET(upload_kind(dim, dim, up_o));
+    ffn_norm = reinterpret_cast<const float*>(p);   p += L * dim * 4;
+    ST_RET(upload_kind(hid, dim, up_1));
+    ST_RET(upload_kind(dim, hid, up_2));
+    ST_RET(upload_kind(hid, dim, up_3));
+    final_norm = reinterpret_cast<const float*>(p); p += dim * 4;
+    p += (size_t)mc.seq_len * c.head_size * 4;  // freqs_cos + freqs_sin, skipped (llama3.cpp:384-385)
+    cls_w = shared ? reinterpret_cast<const uint8_t*>(emb) : p;
+    if (!shared) p += V * dim * 4;
+  } else {
+    // tools/export_llama.py:153-203
+    ST_RET(upload_kind(dim, dim, up_q));
+    ST_RET(upload_kind(kvd, dim, up_k));
+    ST_RET(upload_kind(kvd, dim, up_v));
+    ST_RET(upload_kind(dim, dim, up_o));
+    ST_RET(upload_kind(hid, dim, up_1));
+    ST_RET(upload_kind(dim, hid, up_2));
+    ST_RET(upload_kind(hid, dim, up_3));
+    cls_w = p;
+    cls_s = reinterpret_cast<const float*>(p + V * dim);
+    p += msize(V, dim);
+    emb = reinterpret_cast<const float*>(p);        p += V * dim * 4;
+    attn_norm = reinterpret_cast<const float*>(p);  p += L * dim * 4;
+    ffn_norm = reinterpret_cast<const float*>(p);   p += L * dim * 4;
+    final_norm = reinterpret_cast<const float*>(p); p += dim * 4;
+  }
+  if (p > end) return base::error::ModelParseError("blob truncated");
+  ST_RET(upload_matrix(cls_, 0, cls_w, cls_s, V, dim, 0, V, 0, dim));
+  KX_RET(kx_memcpy_h2d(emb_, emb, V * dim * 4, nullptr));
+  for (size_t l = 0; l < L; ++l) {
+    KX_RET(kx_memcpy_h2d(layers_[l].attn_norm, reinterpret_cast<const uint8_t*>(attn_norm) + l * dim * 4,
+                         dim * 4, nullptr));
+    KX_RET(kx_memcpy_h2d(layers_[l].ffn_norm, reinterpret_cast<const uint8_t*>(ffn_norm) + l * dim * 4,
+                         dim * 4, nullptr));
+  }
+  KX_RET(kx_memcpy_h2d(final_norm_, final_norm, dim * 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::read_weight(const std::string& name, int32_t layer, void* host_out,
+                                     size_t bytes) const {
+  const TransformerConfig& c = cfg_;
+  const size_t esz = quant_ ? 1 : 4;
+  const void* src = nullptr;
+  size_t n = 0;
+  auto sub = [&](const Linear& l, int32_t row_off, int32_t rows, bool scales) {
+    if (scales) {
+      if (!quant_) return;
+      src = l.s + (size_t)row_off * (l.cols / c.group_size);
+      n = (size_t)rows * (l.cols / c.group_size) * 4;
+    } else {
+      src = static_cast<const uint8_t*>(l.w) + (size_t)row_off * l.cols * esz;
+      n = (size_t)rows * l.cols * esz;
+    }
+  };
+  std::string base_name = name;
+  bool scales = false;
+  if (name.size() > 2 && name.substr(name.size() - 2) == "_s") {
+    scales = true;
+    base_name = name.substr(0, name.size() - 2);
+  }
+  if (base_name == "emb") { src = emb_; n = (size_t)c.vocab_size * c.dim * 4; }
+  else if (base_name == "final_norm") { src = final_norm_; n = (size_t)c.dim * 4; }
+  else if (base_name == "cls") sub(cls_, 0, cls_.rows, scales);
+  else {
+    if (layer < 0 || layer >= c.layer_num) return base::error::InvalidArgument("layer out of range");
+    const LayerWeights& lw = layers_[layer];
+    if (base_name == "attn_norm") { src = lw.attn_norm; n = (size_t)c.dim * 4; }
+    else if (base_name == "ffn_norm") { src = lw.ffn_norm; n = (size_t)c.dim * 4; }
+    else if (base_name == "wq") sub(lw.qkv, 0, c.q_dim_local, scales);
+    else if (base_name == "wk") sub(lw.qkv, c.q_dim_local, c.kv_dim_local, scales);
+    else if (base_name == "wv") sub(lw.qkv, c.q_dim_local + c.kv_dim_local, c.kv_dim_local, scales);
+    else if (base_name == "wo") sub(lw.wo, 0, lw.wo.rows, scales);
+    else if (base_name == "w1") sub(lw.w13, 0, c.hidden_local, scales);
+    else if (base_name == "w3") sub(lw.w13, c.hidden_local, c.hidden_local, scales);
+    else if (base_name == "w2") sub(lw.w2, 0, lw.w2.rows, scales);
+  }
+  if (!src) return base::error::InvalidArgument("unknown weight name " + name);
+  if (bytes != n)
+    return base::error::InvalidArgument("weight " + name + " is " + std::to_string(n) + " bytes");
+  KX_RET(kx_device_sync());
+  KX_RET(kx_memcpy_d2h(host_out, src, n, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::init_comm(const base::CommUniqueId* id) {
+  return base::RcclHandler::get_instance()->Init(cfg_.tp_rank, cfg_.tp_size, id);
+}
+
+double LlamaModel::linear_weight_bytes_per_token() const {
+  if (!quant_) return 0.0;
+  double b = 0;
+  const int gs = cfg_.group_size;
+  for (const auto& l : layers_) {
+    b += gemv_bytes(l.qkv.rows, l.qkv.cols, gs) + gemv_bytes(l.wo.rows, l.wo.cols, gs) +
+         gemv_bytes(l.w13.rows, l.w13.cols, gs) + gemv_bytes(l.w2.rows, l.w2.cols, gs);
+  }
+  return b + gemv_bytes(cls_.rows, cls_.cols, gs);
+}
+
+// ---------------- reference-structured path ----------------
+void LlamaModel::build_layers() {
+  const TransformerConfig& c = cfg_;
+  ref_ = std::make_unique<RefLayers>();
+  RefLayers& R = *ref_;
+  const base::DataType wdt = quant_ ? base::DataType::kDataTypeInt8 : base::DataType::kDataTypeFp32;
+  const size_t esz = quant_ ? 1 : 4;
+  auto make = [&](const Linear& l, int32_t row_off, int32_t rows, bool all_reduce) {
+    auto m = std::make_shared<op::MatmulLayer>(kHip, rows, l.cols, quant_);
+    m->set_cuda_config(hip_);
+    uint8_t* w = static_cast<uint8_t*>(l.w) + (size_t)row_off * l.cols * esz;
+    if (quant_) {
+      m->set_group_size(c.group_size);
+      // weights and scales live in separate device arrays here, so bind them one by one
+      // (set_weight(idx, Tensor) + set_scales) instead of the one-blob form
+      STATUS_CHECK(m->set_weight(0, view(wdt, {rows, l.cols}, w)));
+      const int32_t lg = l.cols / c.group_size;
+      m->set_scales(view(base::DataType::kDataTypeFp32, {rows * lg}, l.s + (size_t)row_off * lg));
+    } else {
+      STATUS_CHECK(m->set_weight(0, view(wdt, {rows, l.cols}, w)));
+    }
+    m->set_tp_config(c.tp_size, c.tp_rank, all_reduce);
+    return m;
+  };
+  for (int l = 0; l < c.layer_num; ++l) {
+    const LayerWeights& lw = layers_[l];
+    R.wq.push_back(make(lw.qkv, 0, c.q_dim_local, false));
+    R.wk.push_back(make(lw.qkv, c.q_dim_local, c.kv_dim_local, false));
+    R.wv.push_back(make(lw.qkv, c.q_dim_local + c.kv_dim_local, c.kv_dim_local, false));
+    R.wo.push_back(make(lw.wo, 0, c.dim, true));
+    R.w1.push_back(make(lw.w13, 0, c.hidden_local, false));
+    R.w3.push_back(make(lw.w13, c.hidden_local, c.hidden_local, false));
+    R.w2.push_back(make(lw.w2, 0, c.dim, true));
+  }
+  R.cls = make(cls_, 0, c.vocab_size, false);
+  auto norm = [&](float* w) {
+    auto n = std::make_shared<op::RmsNormLayer>(kHip, c.dim);
+    n->set_cuda_config(hip_);
+    STATUS_CHECK(n->set_weight(0, view(base::DataType::kDataTypeFp32, {c.dim}, w)));
+    return n;
+  };
+  // order as llama3.cpp:296-304: attention norms, ffn norms, final norm
+  for (int l = 0; l < c.layer_num; ++l) R.rmsnorm.push_back(norm(layers_[l].attn_norm));
+  for (int l = 0; l < c.layer_num; ++l) R.rmsnorm.push_back(norm(layers_[l].ffn_norm));
+  R.rmsnorm.push_back(norm(final_norm_));
+  R.rope = std::make_shared<op::RoPELayer>(kHip, c.q_dim_local, c.kv_dim_local, c.head_size);
+  R.mha = std::make_shared<op::MultiHeadAttention>(kHip, 0, c.kv_mul, c.kv_dim_local, c.seq_len,
+                                                   c.head_local, c.head_size);
+  R.add = std::make_shared<op::VecAddLayer>(kHip);
+  R.swiglu = std::make_shared<op::SwiGLULayer>(kHip, c.hidden_local);
+  R.embedding = std::make_shared<op::EmbeddingLayer>(kHip, c.dim, c.seq_len, c.vocab_size);
+  STATUS_CHECK(R.embedding->set_weight(
+      0, view(base::DataType::kDataTypeFp32, {c.vocab_size, c.dim}, emb_)));
+  for (op::Layer* l : std::initializer_list<op::Layer*>{R.rope.get(), R.mha.get(), R.add.get(),
+                                                        R.swiglu.get(), R.embedding.get()})
+    l->set_cuda_config(hip_);
+
+  // activation buffers, named as the reference's buffer map (llama3.cpp:460-536)
+  using B = ModelBufferType;
+  auto f32 = [&](std::vector<int32_t> dims, float* p) {
+    return view(base::DataType::kDataTypeFp32, std::move(dims), p);
+  };
+  R.buffers[B::kInputEmbeddings] = f32({1, c.dim}, x_);
+  R.buffers[B::kOutputRMSNorm] = f32({c.dim}, rms_);
+  R.buffers[B::kFFNRMSNorm] = f32({c.dim}, rms_);
+  R.buffers[B::kW2Output] = f32({c.dim}, tmp_dim_);
+  R.buffers[B::kAttnOutput] = f32({c.dim}, tmp_dim_);
+  R.buffers[B::kQuery] = f32({c.q_dim_local}, q_);
+  R.buffers[B::kOutputMHA] = f32({c.q_dim_local}, att_);
+  R.buffers[B::kW1Output] = f32({c.hidden_local}, h_);
+  R.buffers[B::kW3Output] = f32({c.hidden_local}, h3_);
+  R.buffers[B::kSinCache] = f32({c.head_size * c.seq_len}, sin_);
+  R.buffers[B::kCosCache] = f32({c.head_size * c.seq_len}, cos_);
+  R.buffers[B::kForwardOutput] = f32({c.vocab_size}, logits_);
+  R.buffers[B::kKeyCache] = f32({c.layer_num, c.seq_len, c.kv_dim_local},
+                                static_cast<float*>(kv_->get_raw_buffer_k()));
+  R.buffers[B::kValueCache] = f32({c.layer_num, c.seq_len, c.kv_dim_local},
+                                  static_cast<float*>(kv_->get_raw_buffer_v()));
+  R.buffers[B::kScoreStorage] =
+      view(base::DataType::kDataTypeFp32, {c.head_local, c.seq_len}, hip_->attn_workspace);
+  auto cpu = base::CPUDeviceAllocatorFactory::get_instance();
+  R.pos_tensor = tensor::Tensor(base::DataType::kDataTypeInt32, 1, true, cpu);
+  R.token_tensor = tensor::Tensor(base::DataType::kDataTypeInt32, 1, true, cpu);
+  R.token_num = tensor::Tensor(base::DataType::kDataTypeInt32, 1, true, cpu);
+}
+
+base::Status LlamaModel::forward_layers(int32_t token, int32_t pos, float* logits_host) {
+  using B = ModelBufferType;
+  RefLayers& R = *ref_;
+  const TransformerConfig& c = cfg_;
+  if (pos < 0 || pos >= c.seq_len) return base::error::InvalidArgument("pos outside seq_len");
+  auto& buf = R.buffers;
+  R.pos_tensor.index<int32_t>(0) = pos;
+  R.token_tensor.index<int32_t>(0) = token;
+  tensor::Tensor x = view(base::DataType::kDataTypeFp32, {c.dim}, x_);
+  // embedding (llama3.cpp:615-635)
+  ST_RET(R.embedding->forward(R.token_tensor, R.token_num, buf[B::kInputEmbeddings]));
+  for (int32_t l = 0; l < c.layer_num; ++l) {
+    // attention_rms (llama3.cpp:637-646)
+    ST_RET(R.rmsnorm[l]->forward(x, buf[B::kOutputRMSNorm]));
+    // attention_qkv (:648-677): k and v are written straight into their cache row
+    auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
+    tensor::Tensor key = view(base::DataType::kDataTypeFp32, {c.kv_dim_local},
+                              static_cast<float*>(k_ptr) + (size_t)pos * c.kv_dim_local);
+    tensor::Tensor val = view(base::DataType::kDataTypeFp32, {c.kv_dim_local},
+                              static_cast<float*>(v_ptr) + (size_t)pos * c.kv_dim_local);
+    ST_RET(R.wq[l]->forward(buf[B::kOutputRMSNorm], buf[B::kQuery]));
+    ST_RET(R.wk[l]->forward(buf[B::kOutputRMSNorm], key));
+    ST_RET(R.wv[l]->forward(buf[B::kOutputRMSNorm], val));
+    ST_RET(R.rope->forward(buf[B::kQuery], key, R.pos_tensor, buf[B::kSinCache], buf[B::kCosCache],
+                           tensor::Tensor{}));
+    // attention_mha (:716-743)
+    R.mha->set_pos(pos);
+    R.mha->set_layer_idx(l);
+    ST_RET(R.mha->forward(buf[B::kQuery], buf[B::kScoreStorage], buf[B::kKeyCache],
+                          buf[B::kValueCache], buf[B::kOutputMHA]));
+    ST_RET(R.wo[l]->forward(buf[B::kOutputMHA], buf[B::kAttnOutput]));
+    // feed_forward (:746-788)
+    ST_RET(R.add->forward(x, buf[B::kAttnOutput], x));
+    ST_RET(R.rmsnorm[l + c.layer_num]->forward(x, buf[B::kFFNRMSNorm]));
+    ST_RET(R.w1[l]->forward(buf[B::kFFNRMSNorm], buf[B::kW1Output]));
+    ST_RET(R.w3[l]->forward(buf[B::kFFNRMSNorm], buf[B::kW3Output]));
+    ST_RET(R.swiglu->forward(buf[B::kW1Output], buf[B::kW3Output], buf[B::kW1Output]));
+    ST_RET(R.w2[l]->forward(buf[B::kW1Output], buf[B::kW2Output]));
+    ST_RET(R.add->forward(x, buf[B::kW2Output], x));
+  }
+  // cls_logits (:790-799)
+  ST_RET(R.rmsnorm[2 * c.layer_num]->forward(x, x));
+  ST_RET(R.cls->forward(x, buf[B::kForwardOutput]));
+  if (logits_host) {
+    KX_RET(kx_stream_sync(hip_->stream));
+    KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)c.vocab_size * 4, nullptr));
+  }
+  return base::error::Success();
+}
+
+// ---------------- fused path ----------------
+base::Status LlamaModel::gemv(const Linear& l, int mode, const float* x, const float* norm_w,
+                              float* y0, float* y1, float* y2, int32_t k0, int32_t k1,
+                              const float* residual, void* stream) {
+  kx_gemv_w8_desc d{};
+  d.mode = mode;
+  d.group_size = cfg_.group_size;
+  d.M = l.cols;
+  d.K = l.rows;
+  d.x = x;
+  d.w = static_cast<const int8_t*>(l.w);
+  d.scales = l.s;
+  d.norm_w = norm_w;
+  d.norm_eps = cfg_.rms_eps;
+  d.y0 = y0; d.y1 = y1; d.y2 = y2;
+  d.k0 = k0; d.k1 = k1;
+  d.bias = l.bias;
+  d.residual = residual;
+  if (mode == KX_GEMV_QKV_ROPE) {
+    d.sin_cache = sin_;
+    d.cos_cache = cos_;
+    d.pos_dev = pos_dev_;
+    d.rope_variant = cfg_.rope_variant;
+    d.head_size = cfg_.head_size;
+    d.kv_pos_stride = cfg_.kv_dim_local;
+  }
+  void *e0 = nullptr, *e1 = nullptr;
+  if (prof_on_) {
+    if (prof_cursor_ >= prof_events_.size()) {
+      void *a = nullptr, *b = nullptr;
+      KX_RET(kx_event_create(&a));
+      KX_RET(kx_event_create(&b));
+      prof_events_.push_back({a, b});
+      prof_bytes_.push_back(0);
+    }
+    e0 = prof_events_[prof_cursor_].first;
+    e1 = prof_events_[prof_cursor_].second;
+    prof_bytes_[prof_cursor_] = gemv_bytes(l.rows, l.cols, cfg_.group_size);
+    ++prof_cursor_;
+    KX_RET(kx_event_record(e0, stream));
+  }
+  KX_RET(kx_gemv_w8_fused_f32(&d, stream));
+  if (prof_on_) KX_RET(kx_event_record(e1, stream));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::all_reduce(float* buf, size_t count) {
+  if (cfg_.tp_size <= 1) return base::error::Success();
+  auto comm = base::RcclHandler::get_instance();
+  // all-reduce on the side stream between two reused events (matmul.cpp:93-116)
+  KX_RET(kx_event_record(hip_->compute_done, hip_->stream));
+  KX_RET(kx_stream_wait_event(hip_->comm_stream, hip_->compute_done));
+  ST_RET(comm->AllReduce(buf, buf, count, base::DataType::kDataTypeFp32, hip_->comm_stream));
+  KX_RET(kx_event_record(hip_->comm_done, hip_->comm_stream));
+  KX_RET(kx_stream_wait_event(hip_->stream, hip_->comm_done));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::launch_step(void* st, bool sample) {
+  const TransformerConfig& c = cfg_;
+  if (!quant_) return base::error::FunctionNotImplement("the fused path needs int8 weights");
+  KX_RET(kx_embedding_dpos_f32(history_dev_, pos_dev_, emb_, c.dim, c.vocab_size, x_, st));
+  const int32_t ql = c.q_dim_local, kl = c.kv_dim_local;
+  for (int32_t l = 0; l < c.layer_num; ++l) {
+    const LayerWeights& lw = layers_[l];
+    auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
+    ST_RET(gemv(lw.qkv, KX_GEMV_QKV_ROPE, x_, lw.attn_norm, q_, static_cast<float*>(k_ptr),
+                static_cast<float*>(v_ptr), ql, ql + kl, nullptr, st));
+    KX_RET(kx_mha_decode_dpos_f32(q_, static_cast<float*>(kv_->get_raw_buffer_k()),
+                                  static_cast<float*>(kv_->get_raw_buffer_v()), att_, pos_dev_,
+                                  c.seq_len - 1, c.head_local, c.kv_mul, c.head_size, kl, c.seq_len,
+                                  l, hip_->attn_workspace, hip_->attn_workspace_bytes, st));
+    // row-parallel: every rank holds a partial sum; rank 0 carries the residual into the sum
+    const float* res = c.tp_rank == 0 ? x_ : nullptr;
+    ST_RET(gemv(lw.wo, KX_GEMV_PLAIN, att_, nullptr, x_, nullptr, nullptr, 0, 0, res, st));
+    ST_RET(all_reduce(x_, c.dim));
+    ST_RET(gemv(lw.w13, KX_GEMV_GATE_UP, x_, lw.ffn_norm, h_, nullptr, nullptr, 0, 0, nullptr, st));
+    ST_RET(gemv(lw.w2, KX_GEMV_PLAIN, h_, nullptr, x_, nullptr, nullptr, 0, 0, res, st));
+    ST_RET(all_reduce(x_, c.dim));
+  }
+  ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_, final_norm_, logits_, nullptr, nullptr, 0, 0, nullptr, st));
+  // greedy sample; a prompt step keeps the given next token and only advances the position
+  KX_RET(kx_decode_step_end(logits_, c.vocab_size, token_dev_, pos_dev_,
+                            sample ? history_dev_ : nullptr, c.seq_len + 1, st));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::set_state(int32_t token, int32_t pos) {
+  if (pos < 0 || pos >= cfg_.seq_len) return base::error::InvalidArgument("pos outside seq_len");
+  KX_RET(kx_stream_sync(hip_->stream));
+  KX_RET(kx_memcpy_h2d(token_dev_, &token, 4, nullptr));
+  KX_RET(kx_memcpy_h2d(pos_dev_, &pos, 4, nullptr));
+  KX_RET(kx_memcpy_h2d(history_dev_ + pos, &token, 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::step_logits(int32_t token, int32_t pos, float* logits_host) {
+  ST_RET(set_state(token, pos));
+  ST_RET(launch_step(hip_->stream, true));
+  KX_RET(kx_stream_sync(hip_->stream));
+  if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)cfg_.vocab_size * 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::decode(int32_t steps, bool use_graph) {
+  if (steps <= 0) return base::error::Success();
+  int32_t pos = 0;
+  KX_RET(kx_stream_sync(hip_->stream));
+  KX_RET(kx_memcpy_d2h(&pos, pos_dev_, 4, nullptr));
+  if (pos + steps > cfg_.seq_len)
+    return base::error::InvalidArgument("decode would run past seq_len");
+  void* st = hip_->stream;
+  if (use_graph) {
+    if (!graph_) {
+      // one eager step first: lazy per-kernel setup (e.g. raising a kernel's LDS limit) must
+      // not happen while the stream is capturing
+      ST_RET(launch_step(st, true));
+      --steps;
+      KX_RET(kx_graph_begin_capture(st));
+      base::Status s = launch_step(st, true);
+      void* g = nullptr;
+      const int rc = kx_graph_end_capture(st, &g);
+      if (!s) return s;
+      KX_RET(rc);
+      graph_ = g;
+    }
+    for (int32_t i = 0; i < steps; ++i) KX_RET(kx_graph_launch(graph_, st));
+  } else {
+    for (int32_t i = 0; i < steps; ++i) ST_RET(launch_step(st, true));
+  }
+  return base::error::Success();
+}
+
+base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host) {
+  if (!tokens || n <= 0 || pos0 < 0 || pos0 + n > cfg_.seq_len)
+    return base::error::InvalidArgument("prompt does not fit in seq_len");
+  // The prompt is laid into the token history; each row then runs the fused step without
+  // sampling.  (The reference feeds the prompt one token per predict() as well,
+  // demo/main.cpp:18-41.)
+  KX_RET(kx_stream_sync(hip_->stream));
+  KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
+  KX_RET(kx_memcpy_h2d(pos_dev_, &pos0, 4, nullptr));
+  for (int32_t i = 0; i < n; ++i) ST_RET(launch_step(hip_->stream, false));
+  KX_RET(kx_stream_sync(hip_->stream));
+  // leave the state ready for decode(): the sampled token of the last prompt row
+  int32_t next = 0;
+  KX_RET(kx_memcpy_d2h(&next, token_dev_, 4, nullptr));
+  KX_RET(kx_memcpy_h2d(history_dev_ + pos0 + n, &next, 4, nullptr));
+  if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)cfg_.vocab_size * 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::read_history(int32_t* out, int32_t n) const {
+  if (!out || n < 0 || n > cfg_.seq_len + 1) return base::error::InvalidArgument("bad history range");
+  KX_RET(kx_stream_sync(hip_->stream));
+  KX_RET(kx_memcpy_d2h(out, history_dev_, (size_t)n * 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::read_state(int32_t* token, int32_t* pos) const {
+  KX_RET(kx_stream_sync(hip_->stream));
+  if (token) KX_RET(kx_memcpy_d2h(token, token_dev_, 4, nullptr));
+  if (pos) KX_RET(kx_memcpy_d2h(pos, pos_dev_, 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::read_kv(int32_t layer, int32_t rows, float* k_host, float* v_host) const {
+  if (layer < 0 || layer >= cfg_.layer_num || rows < 0 || rows > cfg_.seq_len)
+    return base::error::InvalidArgument("bad kv range");
+  auto [k_ptr, v_ptr] = kv_->get_cache_ptr(layer);
+  KX_RET(kx_stream_sync(hip_->stream));
+  const size_t n = (size_t)rows * cfg_.kv_dim_local * 4;
+  if (k_host) KX_RET(kx_memcpy_d2h(k_host, k_ptr, n, nullptr));
+  if (v_host) KX_RET(kx_memcpy_d2h(v_host, v_ptr, n, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::sync() const {
+  KX_RET(kx_stream_sync(hip_->stream));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::profile_gemv(int32_t steps, int64_t* launches, double* bytes, double* ms) {
+  int32_t token = 0, pos = 0;
+  ST_RET(read_state(&token, &pos));
+  if (pos + steps > cfg_.seq_len) return base::error::InvalidArgument("profile would run past seq_len");
+  int64_t n = 0;
+  double b = 0, t = 0;
+  for (int32_t i = 0; i < steps; ++i) {
+    prof_on_ = true;
+    prof_cursor_ = 0;
+    base::Status s = launch_step(hip_->stream, true);
+    prof_on_ = false;
+    ST_RET(s);
+    KX_RET(kx_stream_sync(hip_->stream));
+    for (size_t j = 0; j < prof_cursor_; ++j) {
+      float e = 0;
+      KX_RET(kx_event_elapsed_ms(prof_events_[j].first, prof_events_[j].second, &e));
+      t += e;
+      b += prof_bytes_[j];
+      ++n;
+    }
+  }
+  if (launches) *launches = n;
+  if (bytes) *bytes = b;
+  if (ms) *ms = t;
+  return base::error::Success();
+}
+
+}  // namespace model

@@ -62,6 +62,8 @@ SIGNATURES = {
     "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _sz, _vp]),
+    "kx_mha_decode_dpos_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                         _i32, _i32, _vp, _sz, _vp]),
     "kx_flash_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _i32, _f, _i32, _vp, _sz, _vp]),
     "kx_rmsnorm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
@@ -70,7 +72,13 @@ SIGNATURES = {
     "kx_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "kx_add_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "kx_embedding_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "kx_embedding_dpos_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "kx_argmax_f32": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "kx_decode_step_end": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "kx_gemv_w8_fused_f32": (C.c_int, [_vp, _vp]),
+    "kx_fill_hash_i8": (C.c_int, [_vp, _i32, _i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _vp]),
+    "kx_fill_hash_f32": (C.c_int, [_vp, _i32, _i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _f,
+                                   _f, _vp]),
     "kx_comm_unique_id": (C.c_int, [_vp]),
     "kx_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32]),
     "kx_comm_destroy": (C.c_int, [_vp]),
