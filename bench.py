@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy decode of a W8A16 group-quant Llama-family model, batch 1, on
+MI355X, tensor-parallel over N GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--model llama-3-8b] [--context 4096]
+
+A "step" is one decode token: one pass of the hot path (every W8 GEMV of the model + the
+flash-decode attention over the KV cache) with token id and position resident on the device.
+Weights are seeded synthetic int8 + fp32 group scales generated in HBM, the prompt is synthetic
+token ids.  Rank 0 prints ONE JSON line.
+
+N > 1 is launched by torch.distributed.run (one process per GPU); torch is used only for the
+process group (gloo: rendezvous, barrier, max-reduce of the timing, shipping the RCCL unique id).
+The data path -- kernels and the RCCL all-reduce on a side stream -- is the library's own.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
+    """Times the CPU oracle's W8 GEMV (the port of the reference formula) on the host cores on a
+    bounded sample: the model's widest layer matrix, repeated until ~budget_s has elapsed."""
+    from kx import host
+    from oracle import kxo
+    shape = host.MODEL_SHAPES[model_name]
+    K, M = min(shape["hidden_dim"], 14336), shape["dim"]
+    rng = np.random.default_rng(0)
+    w = rng.integers(-127, 128, size=(K, M), dtype=np.int8)
+    s = rng.uniform(1e-4, 3e-4, size=K * M // group_size).astype(np.float32)
+    x = rng.standard_normal(M).astype(np.float32)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    per_call = K * M + 4 * K * M // group_size + 4 * (M + K)
+    out = {}
+    for label, threads in (("1", 1), ("all", cores)):
+        kxo.gemv_w8(x, w, s, group_size, threads=threads)  # warm
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s / 2:
+            kxo.gemv_w8(x, w, s, group_size, threads=threads)
+            n += 1
+        dt = time.perf_counter() - t0
+        out[label] = per_call * n / dt
+    return {
+        "value": out["all"] / bytes_per_token,
+        "unit": "tok/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle kxo_gemv_w8 on a {K}x{M} int8 matrix (gs {group_size}) repeated for "
+                  f"~{budget_s / 2:.0f}s per setting; tok/s = measured GEMV bytes/s / linear-weight "
+                  f"bytes per token ({bytes_per_token / 1e9:.3f} GB); attention excluded",
+        "gemv_gbps_all_cores": out["all"] / 1e9,
+        "gemv_gbps_1_thread": out["1"] / 1e9,
+        "tok_per_s_1_thread": out["1"] / bytes_per_token,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--context", type=int, default=4096,
+                    help="prompt length filled into the KV cache before the timed decode")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch
+    import kx
+    from kx import host
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    kx.check(kx.lib().kx_set_device(local_rank), "kx_set_device")
+    torch.cuda.set_device(local_rank)
+
+    shape = host.MODEL_SHAPES[args.model]
+    seq_len = args.context + args.warmup + args.steps + args.profile_steps + 64
+    seq_len = (seq_len + 63) // 64 * 64
+    model = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, **shape)
+    model.init_synthetic(1234)
+    if world > 1:
+        ids = [host.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        model.init_comm(ids[0])
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    rng = np.random.default_rng(42)
+    prompt = rng.integers(0, shape["vocab_size"], args.context).astype(np.int32)
+    fence()
+    t0 = time.perf_counter()
+    if args.context > 0:
+        model.prefill(prompt)
+    else:
+        model.set_state(int(rng.integers(0, shape["vocab_size"])), 0)
+    fence()
+    prefill_s = time.perf_counter() - t0
+
+    use_graph = not args.no_graph
+    model.decode(max(args.warmup, 2), use_graph=use_graph)  # untimed; also captures the graph
+    fence()
+    t0 = time.perf_counter()
+    model.decode(args.steps, use_graph=use_graph)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the W8 GEMV.  Per-launch HIP events on the compute stream, eager launches.
+    n_launch, gemv_bytes, gemv_ms = model.profile_gemv(args.profile_steps)
+    fence()
+    tok, pos = model.state()
+
+    if rank == 0:
+        bpt = model.linear_bytes_per_token() * world  # whole-model linear bytes per token
+        achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
+        kv_bytes = 2 * shape["layer_num"] * (args.context + args.warmup + args.steps // 2) * \
+            (shape["dim"] // shape["head_num"] * shape["kv_head_num"]) * 4
+        tok_s = args.steps / elapsed
+        line = {
+            "metric": "decode tok/s, W8A16 group-quant, batch 1 (W8A16 GEMV HBM GB/s in roofline)",
+            "value": tok_s,
+            "unit": "tok/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int8 weights x fp32 activations, fp32 accumulate",
+            "data": "synthetic (seeded random-init weights generated on device, random token ids)",
+            "config": {
+                "workload": f"{args.model} W8A16 (group 64) greedy decode, batch 1, "
+                            f"{args.context}-token context, fp32 KV cache",
+                "parallelism": f"tp{world}",
+                "context": args.context,
+                "graph_replay": use_graph,
+                "final_pos": pos,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "gemv_w8_kernel (all W8 GEMV launches of a decode step, per rank)",
+                "launches_timed": n_launch,
+                "algorithmic_bytes_per_launch": gemv_bytes / max(n_launch, 1),
+                "avg_launch_us": gemv_ms * 1e3 / max(n_launch, 1),
+            },
+            "decode_hbm_gbps_end_to_end": (bpt + kv_bytes) * tok_s / 1e9 / world,
+            "prefill_tok_per_s": args.context / prefill_s if args.context else None,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model, bpt)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

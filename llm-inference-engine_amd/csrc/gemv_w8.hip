@@ -76,6 +76,41 @@ __device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, flo
   }
 }
 
+// Issues the 128-bit weight loads (and the one scale per load) of U chunks of R rows.
+template <int R, int U, int R2, int U2, int MODE>
+__device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, int row_end,
+                                           int col_lane, i32x4 (&wv)[R][U], float (&sc)[R][U],
+                                           i32x4 (&wv2)[R2][U2], float (&sc2)[R2][U2]) {
+  constexpr bool GU = MODE == GEMV_GATE_UP;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int col = (c0 + u) * 1024 + col_lane;
+      if (col < a.M) {
+        const size_t off = (size_t)row * (size_t)a.M + (size_t)col;
+        wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
+        sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
+                                              (col >> a.gs_shift));
+        if constexpr (GU) {
+          const size_t off2 = off + (size_t)a.swiglu_half * (size_t)a.M;
+          wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
+          sc2[r][u] = __builtin_nontemporal_load(
+              a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
+        }
+      } else {
+        wv[r][u] = i32x4{0, 0, 0, 0};
+        sc[r][u] = 0.f;
+        if constexpr (GU) {
+          wv2[r][u] = i32x4{0, 0, 0, 0};
+          sc2[r][u] = 0.f;
+        }
+      }
+    }
+  }
+}
+
 // R rows per wave at a time (R even for GEMV_QKV_ROPE), U chunk loads per row in flight.
 template <int R, int U, int MODE>
 __global__ void gemv_w8_kernel(const GemvW8Args a) {
@@ -101,40 +136,9 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
   i32x4 wv2[R2][U2];
   float sc2[R2][U2];
 
-  auto load_batch = [&](int r0, int c0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int col = (c0 + u) * 1024 + col_lane;
-        if (col < M) {
-          const size_t off = (size_t)row * (size_t)M + (size_t)col;
-          wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
-          sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
-                                                (col >> a.gs_shift));
-          if constexpr (GU) {
-            const size_t off2 = off + (size_t)a.swiglu_half * (size_t)M;
-            wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
-            sc2[r][u] = __builtin_nontemporal_load(
-                a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
-          }
-        } else {
-          wv[r][u] = i32x4{0, 0, 0, 0};
-          sc[r][u] = 0.f;
-          if constexpr (GU) {
-            wv2[r][u] = i32x4{0, 0, 0, 0};
-            sc2[r][u] = 0.f;
-          }
-        }
-      }
-    }
-  };
 
-  int r0 = row_begin + wave * R;
-  int c0 = 0;
-  const bool active = r0 < row_end;
-  if (active) load_batch(r0, c0);  // in flight while x is staged
+  const int r_first = row_begin + wave * R;
+  const bool active = r_first < row_end;
 
   // ---- stage x: slot (c*4+p)*64+l  <-  x[c*1024 + l*16 + p*4 .. +4) ; zero past M ----
   {
@@ -172,70 +176,50 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
   int pos = 0;
   if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
 
-  float total[R];
-  float total2[R2];
+  for (int r0 = r_first; r0 < row_end; r0 += nwaves * R) {
+    float total[R];
+    float total2[R2];
 #pragma unroll
-  for (int r = 0; r < R; ++r) total[r] = 0.f;
+    for (int r = 0; r < R; ++r) total[r] = 0.f;
 #pragma unroll
-  for (int r = 0; r < R2; ++r) total2[r] = 0.f;
+    for (int r = 0; r < R2; ++r) total2[r] = 0.f;
 
-  for (;;) {
+    for (int c0 = 0; c0 < a.chunks; c0 += U) {
+      load_batch<R, U, R2, U2, MODE>(a, r0, c0, row_end, col_lane, wv, sc, wv2, sc2);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (c0 + u < a.chunks) {
-        const int base = ((c0 + u) * 4) << 6;
-        const f32x4 x0 = xs[base + lane];
-        const f32x4 x1 = xs[base + 64 + lane];
-        const f32x4 x2 = xs[base + 128 + lane];
-        const f32x4 x3 = xs[base + 192 + lane];
+      for (int u = 0; u < U; ++u) {
+        if (c0 + u < a.chunks) {
+          const int base = ((c0 + u) * 4) << 6;
+          const f32x4 x0 = xs[base + lane];
+          const f32x4 x1 = xs[base + 64 + lane];
+          const f32x4 x2 = xs[base + 128 + lane];
+          const f32x4 x3 = xs[base + 192 + lane];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          total[r] = fmaf(dot16(wv[r][u], x0, x1, x2, x3), sc[r][u], total[r]);
-          if constexpr (GU)
-            total2[r] = fmaf(dot16(wv2[r][u], x0, x1, x2, x3), sc2[r][u], total2[r]);
+          for (int r = 0; r < R; ++r) {
+            total[r] = fmaf(dot16(wv[r][u], x0, x1, x2, x3), sc[r][u], total[r]);
+            if constexpr (GU)
+              total2[r] = fmaf(dot16(wv2[r][u], x0, x1, x2, x3), sc2[r][u], total2[r]);
+          }
         }
       }
     }
-    c0 += U;
-    if (c0 < a.chunks) {
-      load_batch(r0, c0);
-      continue;
-    }
-    // ---- row group finished: start the next group's loads, then reduce and store this one ----
-    const int done_r0 = r0;
-    r0 += nwaves * R;
-    c0 = 0;
-    const bool more = r0 < row_end;
-    float fin[R];
-    float fin2[R2];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      fin[r] = total[r];
-      total[r] = 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < R2; ++r) {
-      fin2[r] = total2[r];
-      total2[r] = 0.f;
-    }
-    if (more) load_batch(r0, c0);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      fin[r] = wave_sum(fin[r]);
+      total[r] = wave_sum(total[r]);
       if constexpr (GU) {
-        const float up = wave_sum(fin2[r]);
+        const float up = wave_sum(total2[r]);
         // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
-        fin[r] = fin[r] * (1.0f / (1.0f + expf(-fin[r]))) * up;
+        total[r] = total[r] * (1.0f / (1.0f + expf(-total[r]))) * up;
       }
     }
     if (lane == 0) {
       if constexpr (MODE == GEMV_QKV_ROPE) {
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
-          const int v = done_r0 + r;
+          const int v = r0 + r;
           if (v < row_end) {  // row counts are even, so v+1 is valid too
             const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
-            float o0 = fin[r], o1 = fin[r + 1];
+            float o0 = total[r], o1 = total[r + 1];
             if (a.bias) {
               o0 += a.bias[row0];
               o1 += a.bias[row1];
@@ -263,9 +247,9 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int row = done_r0 + r;
+          const int row = r0 + r;
           if (row < row_end) {
-            float v = fin[r];
+            float v = total[r];
             if (a.bias) v += a.bias[row];
             if (a.residual) v += a.residual[row];
             float* dst;
@@ -276,7 +260,6 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
         }
       }
     }
-    if (!more) break;
   }
 }
 
