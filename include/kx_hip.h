@@ -213,9 +213,12 @@ int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index, void* stre
 
 /* End of one decode step, on the device (post_processing, llama3.cpp:801-813, without the
  * host round trip): token = argmax(logits); history[pos+1] = token (when history != NULL and in
- * range); pos += 1. */
+ * range); pos += 1.  Two launches (slice-wise argmax, then the reduction and bookkeeping);
+ * `workspace` of kx_step_workspace_bytes() carries the partial results. */
+size_t kx_step_workspace_bytes(void);
 int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev, int32_t* pos_dev,
-                       int32_t* history_dev, int32_t history_len, void* stream);
+                       int32_t* history_dev, int32_t history_len, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Seeded synthetic tensors generated on the device (the benchmarks run on random-init weights;
  * the reference reads real checkpoints through mmap, model.cpp:93-115).  dst is a dense

@@ -180,27 +180,54 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
 }
 
 // out[h][d] = sum_s O_s[d] e^{m_s-M} / sum_s l_s e^{m_s-M}
-__global__ void attn_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int hs,
-                                  int nsplit_grid, int last_val,
-                                  const int32_t* __restrict__ pos_dev) {
+// One 256-thread workgroup per head: the split weights are formed once (one split per lane),
+// then the O rows are summed with the splits dealt over thread groups so the loads of
+// different splits are independent and in flight together.
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws,
+                                                         float* __restrict__ out, int hs,
+                                                         int nsplit_grid, int last_val,
+                                                         const int32_t* __restrict__ pos_dev) {
+  __shared__ float sf[kMaxSplits];
+  __shared__ float red[4];
+  __shared__ float part[256];
   const int hq = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int last = pos_dev ? *pos_dev : last_val;
   const int ntiles = (last >> 4) + 1;
   const int tps = (ntiles + nsplit_grid - 1) / nsplit_grid;
   const int nsplit = (ntiles + tps - 1) / tps;
   if (nsplit == 1) return;  // the attention kernel wrote the final rows itself
-  const float* base = ws + (size_t)hq * nsplit_grid * attn_ws_stride(hs);
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, base[(size_t)s * attn_ws_stride(hs)]);
-  for (int d = threadIdx.x; d < hs; d += blockDim.x) {
-    float L = 0.f, O = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-      const float* p = base + (size_t)s * attn_ws_stride(hs);
-      const float f = expf(p[0] - M);
-      L += p[1] * f;
-      O += p[2 + d] * f;
+  const size_t stride = attn_ws_stride(hs);
+  const float* base = ws + (size_t)hq * nsplit_grid * stride;
+  // nsplit <= kMaxSplits = 64: wave 0 holds one split per lane
+  if (wave == 0) {
+    float m = -INFINITY, l = 0.f;
+    if (lane < nsplit) {
+      m = base[(size_t)lane * stride];
+      l = base[(size_t)lane * stride + 1];
     }
-    out[(size_t)hq * hs + d] = O / L;
+    const float M = wave_max(m);
+    const float f = lane < nsplit ? expf(m - M) : 0.f;
+    sf[lane] = f;
+    const float L = wave_sum(f * l);
+    if (lane == 0) red[0] = L;
+  }
+  __syncthreads();
+  const float inv_l = 1.0f / red[0];
+  // thread (group g, dim d): group g sums splits g, g+G, ...
+  const int G = 256 / hs > 0 ? 256 / hs : 1;
+  const int g = tid / hs, d = tid % hs;
+  float acc = 0.f;
+  if (g < G) {
+#pragma unroll 4
+    for (int s = g; s < nsplit; s += G) acc = fmaf(base[(size_t)s * stride + 2 + d], sf[s], acc);
+  }
+  part[tid] = acc;
+  __syncthreads();
+  if (tid < hs) {
+    float o = 0.f;
+    for (int k = 0; k < G; ++k) o += part[k * hs + tid];
+    out[(size_t)hq * hs + tid] = o * inv_l;
   }
 }
 
@@ -321,8 +348,8 @@ static int mha_decode_launch(const float* query, const float* key_cache, const f
   }
   KX_LAUNCH_CHECK();
   if (nsplit > 1) {
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(head_num), dim3(head_size < 64 ? 64 : head_size), 0,
-                       s, ws, out, head_size, nsplit, pos, pos_dev);
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(head_num), dim3(256), 0, s, ws, out, head_size,
+                       nsplit, pos, pos_dev);
     KX_LAUNCH_CHECK();
   }
   return KX_OK;

@@ -188,19 +188,11 @@ __global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out) 
 // Greedy sampling + bookkeeping of one decode step, all on the device so that a captured token
 // graph can be replayed without the host in the loop: next = argmax(logits) (first maximum
 // wins, argmax_sampler.cpp:6-8); history[pos+1] = next; token = next; pos += 1.
-__global__ void decode_step_end_kernel(const float* __restrict__ x, int n, int32_t* token,
-                                       int32_t* pos, int32_t* history, int history_len) {
-  __shared__ float sv[16];
-  __shared__ int si[16];
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = x[i];
-    if (v > best) {
-      best = v;
-      bi = i;
-    }
-  }
+// Stage 1: kStepBlocks workgroups each reduce a contiguous slice to one (value, index) pair.
+// Stage 2: one workgroup reduces the pairs and does the bookkeeping.
+constexpr int kStepBlocks = 128;
+
+__device__ __forceinline__ void block_argmax(float& best, int& bi, float* sv, int* si) {
   for (int off = 32; off >= 1; off >>= 1) {
     const float ov = __shfl_xor(best, off);
     const int oi = __shfl_xor(bi, off);
@@ -212,8 +204,45 @@ __global__ void decode_step_end_kernel(const float* __restrict__ x, int n, int32
     si[wave] = bi;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0)
     for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
+}
+
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ x, int n,
+                                                             float* __restrict__ pv,
+                                                             int32_t* __restrict__ pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(lo + per, n);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float v = x[i];
+    if (v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+  block_argmax(best, bi, sv, si);
+  if (threadIdx.x == 0) {
+    pv[blockIdx.x] = best;
+    pi[blockIdx.x] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void decode_step_end_kernel(const float* __restrict__ pv,
+                                                              const int32_t* __restrict__ pi,
+                                                              int nparts, int32_t* token,
+                                                              int32_t* pos, int32_t* history,
+                                                              int history_len) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) argmax_merge(best, bi, pv[i], pi[i]);
+  block_argmax(best, bi, sv, si);
+  if (threadIdx.x == 0) {
     if (bi == 0x7fffffff) bi = 0;
     const int p = *pos;
     if (history && p + 1 < history_len) history[p + 1] = bi;
@@ -332,12 +361,21 @@ extern "C" int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index,
   return KX_OK;
 }
 
+extern "C" size_t kx_step_workspace_bytes(void) { return kStepBlocks * 8; }
+
 extern "C" int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev,
                                   int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream) {
   if (!logits || !token_dev || !pos_dev || n <= 0) return KX_EINVAL;
-  hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n,
-                     token_dev, pos_dev, history_dev, history_len);
+  if (!workspace || workspace_bytes < kStepBlocks * 8) return KX_EWORKSPACE;
+  float* pv = reinterpret_cast<float*>(workspace);
+  int32_t* pi = reinterpret_cast<int32_t*>(pv + kStepBlocks);
+  const int blocks = n < kStepBlocks * 256 ? (n + 255) / 256 : kStepBlocks;
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits,
+                     n, pv, pi);
+  KX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pv, pi,
+                     blocks, token_dev, pos_dev, history_dev, history_len);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

@@ -148,6 +148,7 @@ class LlamaModel {
   float *rms_ = nullptr, *h3_ = nullptr, *tmp_dim_ = nullptr;  // layer-path scratch
   float *sin_ = nullptr, *cos_ = nullptr;
   int32_t *token_dev_ = nullptr, *pos_dev_ = nullptr, *history_dev_ = nullptr;
+  float* step_ws_ = nullptr;  // argmax partials of the step-end kernels
   // prefill scratch, grown on demand
   float* pf_ = nullptr;
   size_t pf_bytes_ = 0;

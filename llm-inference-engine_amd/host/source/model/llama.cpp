@@ -115,7 +115,7 @@ LlamaModel::~LlamaModel() {
   dev_free(x_); dev_free(q_); dev_free(att_); dev_free(h_); dev_free(logits_);
   dev_free(rms_); dev_free(h3_); dev_free(tmp_dim_);
   dev_free(sin_); dev_free(cos_);
-  dev_free(token_dev_); dev_free(pos_dev_); dev_free(history_dev_);
+  dev_free(token_dev_); dev_free(pos_dev_); dev_free(history_dev_); dev_free(step_ws_);
   dev_free(pf_);
 }
 
@@ -174,6 +174,7 @@ base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
   ST_RET(dev_alloc(token_dev_, 1));
   ST_RET(dev_alloc(pos_dev_, 1));
   ST_RET(dev_alloc(history_dev_, cfg_.seq_len + 1));
+  ST_RET(dev_alloc(step_ws_, kx_step_workspace_bytes() / sizeof(float)));
   KX_RET(kx_sin_cos_cache_f32(cfg_.head_size, cfg_.seq_len, cfg_.rope_theta, sin_, cos_,
                               hip_->stream));
 
@@ -666,7 +667,8 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
   ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_, final_norm_, logits_, nullptr, nullptr, 0, 0, nullptr, st));
   // greedy sample; a prompt step keeps the given next token and only advances the position
   KX_RET(kx_decode_step_end(logits_, c.vocab_size, token_dev_, pos_dev_,
-                            sample ? history_dev_ : nullptr, c.seq_len + 1, st));
+                            sample ? history_dev_ : nullptr, c.seq_len + 1, step_ws_,
+                            kx_step_workspace_bytes(), st));
   return base::error::Success();
 }
 
