@@ -142,6 +142,13 @@ int kx_gemv_f32(const float* x, const float* w, float* y, int32_t M, int32_t K, 
  * in fp32.  T == 1 forwards to the GEMV. */
 int kx_gemm_w8_f32(const float* X, const int8_t* w, const float* scales, int32_t group_size,
                    float* Y, int32_t T, int32_t M, int32_t K, void* stream);
+/* General form: X rows at stride ldx; output columns [0,k0) -> y0 (row stride ld0), [k0,k1) -> y1,
+ * [k1,K) -> y2 (fused Wq|Wk|Wv with k/v rows landing in consecutive KV-cache rows); `residual`
+ * (nullable, row stride ldr) is added to the y0 columns and may alias y0. */
+int kx_gemm_w8_f32_ex(const float* X, int64_t ldx, const int8_t* w, const float* scales,
+                      int32_t group_size, float* y0, int64_t ld0, float* y1, int64_t ld1, float* y2,
+                      int64_t ld2, int32_t k0, int32_t k1, const float* residual, int64_t ldr,
+                      int32_t T, int32_t M, int32_t K, void* stream);
 int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, int32_t K,
                 void* stream);
 
@@ -199,6 +206,9 @@ int kx_rope_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size,
                 const float* cos_cache, void* stream);
 /* swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): out = in1*sigmoid(in1)*in2. */
 int kx_swiglu_f32(const float* in1, const float* in2, float* out, int32_t n, void* stream);
+/* Row-batched form over a stacked [gate | up] buffer: out[t][h] = silu(in[t][h]) * in[t][half+h]. */
+int kx_swiglu_rows_f32(const float* in, int64_t ld_in, int32_t half, float* out, int64_t ld_out,
+                       int32_t rows, void* stream);
 /* add_kernel_cu (cuda/add_kernel.cu:4-12). */
 int kx_add_f32(const float* a, const float* b, float* out, int32_t n, void* stream);
 /* emb_kernel_cu (cuda/emb_kernel.cu:3-21): tokens on device. */

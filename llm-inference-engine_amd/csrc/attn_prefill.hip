@@ -1,0 +1,343 @@
+// Flash-attention forward over the fp32 KV cache for Tq > 1 query rows (prefill), gfx950.
+//
+// Stands in for flash_attention_fwd_kernel / flash_attention_kernel_cu
+// (kuiper/source/op/kernels/cuda/flash_attention_kernel.cu:40-303).  Semantics are those of the
+// layer interface, not of that kernel (which ignores pos, the layer and GQA): query row i sits at
+// absolute position pos-(Tq-1)+i and attends cache rows 0..that position (causal) or 0..pos.
+//
+// Structure
+//   - one workgroup = one kv head x a block of query rows for ALL the query heads that share the
+//     kv head (wave w -> head w % HPB, 32-row sub-block w / HPB), so a staged K/V tile feeds
+//     kv_mul times more MFMA work than it would per head.
+//   - K/V tiles of 64 keys are read from the fp32 cache, rounded to fp16 and staged in LDS
+//     (K row-major, V transposed), two buffers, one barrier per tile; the next tile's global
+//     loads are issued before the current tile's MFMAs.
+//   - S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_f16.  With the key index on the
+//     register axis and the query row on the lane, the exponentiated score registers are already
+//     the B operand of the second product: probabilities never leave registers, and the
+//     online-softmax state (running max, running sum, rescale factor) is one value per lane.
+//   - fp32 everywhere outside the two MFMA operand roundings (Q*scale, K, V, P to fp16).
+#include <math.h>
+
+#include "kx_common.hpp"
+
+namespace kx {
+
+constexpr int FA_KV = 64;       // keys per tile
+constexpr int FA_VT_ROW = 68;   // halves per padded V^T row (64 keys + 4)
+
+struct FaArgs {
+  const float* q;   // [Tq][H][HS]
+  const float* kc;  // layer base [S][kv_dim]
+  const float* vc;
+  float* out;       // [Tq][H][HS]
+  int32_t Tq, H, kv_mul, kv_dim, pos, causal;
+  int32_t hpb;      // query heads per workgroup (divides kv_mul)
+  int32_t qsubs;    // 32-row sub-blocks per workgroup
+  float scale;
+};
+
+template <int HS>
+__global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
+  constexpr int K_ROW = HS + 8;         // halves per padded K row
+  constexpr int KS = HS / 16;           // 16-dim MFMA steps of Q.K
+  constexpr int DT = HS / 32;           // 32-dim output tiles
+  constexpr int K_TILE = FA_KV * K_ROW; // halves
+  constexpr int V_TILE = HS * FA_VT_ROW;
+  constexpr int BUF = K_TILE + V_TILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* lds = reinterpret_cast<_Float16*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x;
+  const int qcol = lane & 31, half = lane >> 5;
+  const int groups_per_kvh = a.kv_mul / a.hpb;
+  const int kvh = blockIdx.x / groups_per_kvh;
+  const int hgroup = blockIdx.x % groups_per_kvh;
+  const int head = kvh * a.kv_mul + hgroup * a.hpb + (wave % a.hpb);
+  const int rows_per_block = 32 * a.qsubs;
+  // heavy (late, long-context) query blocks first
+  const int qblock = (int)gridDim.y - 1 - (int)blockIdx.y;
+  const int q0_block = qblock * rows_per_block;
+  const int q0 = q0_block + (wave / a.hpb) * 32;       // first query row of this wave
+  const int qpos0 = a.pos - (a.Tq - 1);                // absolute position of query row 0
+  const int my_row = q0 + qcol;
+  const int my_pos = a.causal ? min(qpos0 + my_row, a.pos) : a.pos;
+
+  // keys this workgroup needs: up to the position of its last query row
+  const int last_row_block = min(q0_block + rows_per_block, a.Tq) - 1;
+  const int max_key = a.causal ? qpos0 + last_row_block : a.pos;
+  const int ntiles = max_key / FA_KV + 1;
+
+  // ---- Q fragment (B operand): lane (q row, half) holds Q[row][16ks + 8half + j] * scale ----
+  f16x8 qf[KS];
+  {
+    const bool valid = my_row < a.Tq;
+    const float* qp = a.q + ((size_t)min(my_row, a.Tq - 1) * a.H + head) * HS + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+        v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+      }
+      qf[ks][0] = (_Float16)(v0.x * a.scale);
+      qf[ks][1] = (_Float16)(v0.y * a.scale);
+      qf[ks][2] = (_Float16)(v0.z * a.scale);
+      qf[ks][3] = (_Float16)(v0.w * a.scale);
+      qf[ks][4] = (_Float16)(v1.x * a.scale);
+      qf[ks][5] = (_Float16)(v1.y * a.scale);
+      qf[ks][6] = (_Float16)(v1.z * a.scale);
+      qf[ks][7] = (_Float16)(v1.w * a.scale);
+    }
+  }
+
+  // ---- staging roles ----
+  // K: item = (key, 4-dim group): 64 * HS/4 items.  V: item = (4-key group, 4-dim group).
+  constexpr int K_ITEMS = FA_KV * (HS / 4);
+  constexpr int V_ITEMS = (FA_KV / 4) * (HS / 4);
+  constexpr int MAXT = 256;  // fewest threads a launch uses
+  constexpr int K_PER = (K_ITEMS + MAXT - 1) / MAXT;
+  constexpr int V_PER = (V_ITEMS + MAXT - 1) / MAXT;
+  f32x4 kreg[K_PER];
+  f32x4 vreg[V_PER][4];
+  const float* kbase = a.kc + (size_t)kvh * HS;
+  const float* vbase = a.vc + (size_t)kvh * HS;
+
+  auto load_tile = [&](int t) {
+    const int key0 = t * FA_KV;
+#pragma unroll
+    for (int i = 0; i < K_PER; ++i) {
+      const int item = tid + i * nthreads;
+      if (item < K_ITEMS) {
+        const int key = item / (HS / 4), dg = item % (HS / 4);
+        kreg[i] = *reinterpret_cast<const f32x4*>(
+            kbase + (size_t)min(key0 + key, a.pos) * a.kv_dim + 4 * dg);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V_PER; ++i) {
+      const int item = tid + i * nthreads;
+      if (item < V_ITEMS) {
+        const int kg = item / (HS / 4), dg = item % (HS / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          vreg[i][e] = *reinterpret_cast<const f32x4*>(
+              vbase + (size_t)min(key0 + 4 * kg + e, a.pos) * a.kv_dim + 4 * dg);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    _Float16* Kl = lds + buf * BUF;
+    _Float16* Vl = Kl + K_TILE;
+#pragma unroll
+    for (int i = 0; i < K_PER; ++i) {
+      const int item = tid + i * nthreads;
+      if (item < K_ITEMS) {
+        const int key = item / (HS / 4), dg = item % (HS / 4);
+        f16x4 h;
+        h[0] = (_Float16)kreg[i].x; h[1] = (_Float16)kreg[i].y;
+        h[2] = (_Float16)kreg[i].z; h[3] = (_Float16)kreg[i].w;
+        *reinterpret_cast<f16x4*>(Kl + key * K_ROW + 4 * dg) = h;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V_PER; ++i) {
+      const int item = tid + i * nthreads;
+      if (item < V_ITEMS) {
+        const int kg = item / (HS / 4), dg = item % (HS / 4);
+        // 4 keys x 4 dims in registers -> four 4-key runs of V^T
+        const float vals[4][4] = {{vreg[i][0].x, vreg[i][1].x, vreg[i][2].x, vreg[i][3].x},
+                                  {vreg[i][0].y, vreg[i][1].y, vreg[i][2].y, vreg[i][3].y},
+                                  {vreg[i][0].z, vreg[i][1].z, vreg[i][2].z, vreg[i][3].z},
+                                  {vreg[i][0].w, vreg[i][1].w, vreg[i][2].w, vreg[i][3].w}};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          f16x4 h;
+          h[0] = (_Float16)vals[d][0]; h[1] = (_Float16)vals[d][1];
+          h[2] = (_Float16)vals[d][2]; h[3] = (_Float16)vals[d][3];
+          *reinterpret_cast<f16x4*>(Vl + (4 * dg + d) * FA_VT_ROW + 4 * kg) = h;
+        }
+      }
+    }
+  };
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  constexpr float kLog2e = 1.4426950408889634f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  // tiles past this wave's own last query row contribute nothing to it
+  const int wave_last_pos = a.causal ? min(qpos0 + min(q0 + 31, a.Tq - 1), a.pos) : a.pos;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);
+    const int key0 = t * FA_KV;
+    if (key0 <= wave_last_pos) {
+      const _Float16* Kl = lds + buf * BUF;
+      const _Float16* Vl = Kl + K_TILE;
+      // ---- S^T[key][q] for the tile's two 32-key halves ----
+      f32x16 s[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        const _Float16* kp = Kl + (kt * 32 + qcol) * K_ROW + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + 16 * ks);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+        }
+      }
+      // ---- mask + online softmax (one query row per lane; the other half-wave holds the
+      //      other 32 keys of the same row) ----
+      float mx = -INFINITY;
+      const bool need_mask = key0 + FA_KV - 1 > my_pos;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (need_mask) {
+            const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key > my_pos) s[kt][r] = -INFINITY;
+          }
+          mx = fmaxf(mx, s[kt][r]);
+        }
+      mx = fmaxf(mx, lane_xor32(mx));
+      const float m_new = fmaxf(m_run, mx);
+      // a row whose keys are all masked so far keeps m = -inf; guard the inf - inf
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = exp2f((m_run - m_use) * kLog2e);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = exp2f((s[kt][r] - m_use) * kLog2e);
+          s[kt][r] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      // ---- O^T[d][q] += V^T . P^T ; registers 8s..8s+7 of a score tile are the B fragment of
+      //      16-key step s, element j <-> key 16s + 8(j>>2) + 4half + (j&3) ----
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          f16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (_Float16)s[kt][8 * st + j];
+          const _Float16* vp = Vl + qcol * FA_VT_ROW + kt * 32 + 16 * st + 4 * half;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const f16x4 lo = *reinterpret_cast<const f16x4*>(vp + dt * 32 * FA_VT_ROW);
+            const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + dt * 32 * FA_VT_ROW + 8);
+            f16x8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (q row, half) holds O[row][32dt + 8g + 4half + e] in o[dt][4g+e] ----
+  l_run += lane_xor32(l_run);
+  if (my_row < a.Tq) {
+    const float inv = 1.0f / l_run;
+    float* op = a.out + ((size_t)my_row * a.H + head) * HS + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                   o[dt][4 * g + 3] * inv};
+        *reinterpret_cast<f32x4*>(op + 32 * dt + 8 * g) = v;
+      }
+  }
+}
+
+template <int HS>
+static int launch_prefill(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
+  static bool raised = false;
+  if (lds > 64 * 1024 && !raised) {
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = true;
+  }
+  const dim3 grid(kvh * (a.kv_mul / a.hpb), qblocks);
+  hipLaunchKernelGGL(attn_prefill_kernel<HS>, grid, dim3(threads), lds, s, a);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+}  // namespace kx
+
+extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache,
+                                      const float* value_cache, float* out, int32_t Tq,
+                                      int32_t head_num, int32_t kv_head_num, int32_t head_size,
+                                      int32_t seq_len, int32_t pos, int32_t layer_idx,
+                                      float softmax_scale, int32_t is_causal, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  using namespace kx;
+  if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
+  if (Tq <= 0 || head_num <= 0 || kv_head_num <= 0 || head_num % kv_head_num) return KX_EINVAL;
+  if (pos < 0 || pos >= seq_len || pos - (Tq - 1) < 0) return KX_EINVAL;
+  const int kv_mul = head_num / kv_head_num;
+  const int kv_dim = kv_head_num * head_size;
+  const float default_scale = 1.0f / sqrtf((float)head_size);
+  const bool tiled = (head_size == 32 || head_size == 64 || head_size == 128) &&
+                     (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache |
+                       (uintptr_t)out) % 16 == 0);
+  if (Tq == 1 || !tiled) {
+    // single rows (and head sizes the tiled kernel is not built for) go through the decode
+    // kernel row by row; it takes the default scale only
+    if (fabsf(softmax_scale - default_scale) > 1e-6f * default_scale) return KX_EUNSUPPORTED;
+    for (int32_t i = 0; i < Tq; ++i) {
+      const int32_t p = is_causal ? pos - (Tq - 1) + i : pos;
+      int rc = kx_mha_decode_f32(query + (size_t)i * head_num * head_size, key_cache, value_cache,
+                                 out + (size_t)i * head_num * head_size, p, head_num, kv_mul,
+                                 head_size, kv_dim, seq_len, layer_idx, workspace, workspace_bytes,
+                                 stream);
+      if (rc) return rc;
+    }
+    return KX_OK;
+  }
+  // query heads per workgroup: the largest divisor of kv_mul that fits 8 waves
+  int hpb = 1;
+  for (int d = 1; d <= 8 && d <= kv_mul; ++d)
+    if (kv_mul % d == 0) hpb = d;
+  int qsubs = hpb >= 4 ? 1 : 4 / hpb;
+  if (hpb * qsubs < 4) qsubs = (4 + hpb - 1) / hpb;
+  const int threads = 64 * hpb * qsubs;
+  const size_t layer_off = (size_t)layer_idx * (size_t)seq_len * (size_t)kv_dim;
+  FaArgs a{};
+  a.q = query; a.kc = key_cache + layer_off; a.vc = value_cache + layer_off; a.out = out;
+  a.Tq = Tq; a.H = head_num; a.kv_mul = kv_mul; a.kv_dim = kv_dim; a.pos = pos;
+  a.causal = is_causal ? 1 : 0; a.hpb = hpb; a.qsubs = qsubs; a.scale = softmax_scale;
+  const int qblocks = (Tq + 32 * qsubs - 1) / (32 * qsubs);
+  hipStream_t s = (hipStream_t)stream;
+  switch (head_size) {
+    case 32: return launch_prefill<32>(a, kv_head_num, threads, qblocks, s);
+    case 64: return launch_prefill<64>(a, kv_head_num, threads, qblocks, s);
+    default: return launch_prefill<128>(a, kv_head_num, threads, qblocks, s);
+  }
+}

@@ -109,6 +109,26 @@ __global__ void swiglu_kernel(const float* __restrict__ a, const float* __restri
   out[i] = g * (1.0f / (1.0f + expf(-g))) * b[i];
 }
 
+// Row-batched SwiGLU over a stacked [gate | up] activation: out[t][h] = silu(in[t][h]) *
+// in[t][half + h] (the prefill form of swiglu_kernel_cu_fp32).
+__global__ void swiglu_rows_kernel(const float* __restrict__ in, int64_t ld_in, int half,
+                                   float* __restrict__ out, int64_t ld_out, int rows) {
+  const int64_t n4 = (int64_t)rows * (half / 4);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / (half / 4);
+    const int h = (int)(i - t * (half / 4)) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(in + t * ld_in + h);
+    const f32x4 u = *reinterpret_cast<const f32x4*>(in + t * ld_in + half + h);
+    f32x4 o;
+    o.x = g.x * (1.0f / (1.0f + expf(-g.x))) * u.x;
+    o.y = g.y * (1.0f / (1.0f + expf(-g.y))) * u.y;
+    o.z = g.z * (1.0f / (1.0f + expf(-g.z))) * u.z;
+    o.w = g.w * (1.0f / (1.0f + expf(-g.w))) * u.w;
+    *reinterpret_cast<f32x4*>(out + t * ld_out + h) = o;
+  }
+}
+
 // add_kernel_cu_fp32 (cuda/add_kernel.cu:4-12)
 __global__ void add_kernel(const float* a, const float* b, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,6 +424,16 @@ extern "C" int kx_embedding_dpos_f32(const int32_t* history_dev, const int32_t* 
   if (!history_dev || !pos_dev || !table || !out || dim <= 0 || vocab_size <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(embedding_dpos_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, history_dev,
                      pos_dev, table, out, dim, vocab_size);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_swiglu_rows_f32(const float* in, int64_t ld_in, int32_t half, float* out,
+                                  int64_t ld_out, int32_t rows, void* stream) {
+  if (!in || !out || half <= 0 || rows <= 0) return KX_EINVAL;
+  if (half % 4 || ld_in % 4 || ld_out % 4 || ((uintptr_t)in | (uintptr_t)out) % 16) return KX_EINVAL;
+  hipLaunchKernelGGL(swiglu_rows_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, in, ld_in,
+                     half, out, ld_out, rows);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

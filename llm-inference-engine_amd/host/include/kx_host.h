@@ -33,7 +33,9 @@ int kxm_forward_layers(void* model, int32_t token, int32_t pos, float* logits_ho
 int kxm_set_state(void* model, int32_t token, int32_t pos);
 int kxm_step_logits(void* model, int32_t token, int32_t pos, float* logits_host);
 int kxm_decode(void* model, int32_t steps, int32_t use_graph);
-int kxm_prefill(void* model, const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);
+/* exact = 0: batched MFMA prompt pass; exact = 1: one fp32 decode step per prompt row */
+int kxm_prefill(void* model, const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host,
+                int32_t exact);
 int kxm_read_history(void* model, int32_t* out, int32_t n);
 int kxm_read_state(void* model, int32_t* token, int32_t* pos);
 int kxm_read_kv(void* model, int32_t layer, int32_t rows, float* k_host, float* v_host);

@@ -93,7 +93,10 @@ class LlamaModel {
   base::Status decode(int32_t steps, bool use_graph);           // greedy, host out of the loop
   base::Status read_history(int32_t* out, int32_t n) const;     // token at each position
   base::Status read_state(int32_t* token, int32_t* pos) const;
-  base::Status prefill(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);
+  // Prompt rows pos0..pos0+n-1.  Default: batched (MFMA GEMMs + flash attention, fp16 operand
+  // rounding).  exact = true feeds the rows one by one through the fp32 decode step instead.
+  base::Status prefill(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host,
+                       bool exact = false);
 
   base::Status read_kv(int32_t layer, int32_t rows, float* k_host, float* v_host) const;
   base::Status sync() const;
@@ -127,6 +130,8 @@ class LlamaModel {
   base::Status upload_matrix(Linear& l, int32_t dst_row_off, const void* src_w, const float* src_s,
                              int32_t g_rows, int32_t g_cols, int32_t row0, int32_t rows,
                              int32_t col0, int32_t cols);
+  static constexpr int32_t kPrefillChunk = 4096;  // prompt rows per batched pass
+  base::Status prefill_sequential(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);
   void build_layers();
   base::Status launch_step(void* stream, bool with_events);
   base::Status gemv(const Linear& l, int mode, const float* x, const float* norm_w, float* y0,

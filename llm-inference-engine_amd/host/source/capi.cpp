@@ -72,8 +72,9 @@ int kxm_step_logits(void* m, int32_t token, int32_t pos, float* logits) {
   return done(M(m)->step_logits(token, pos, logits));
 }
 int kxm_decode(void* m, int32_t steps, int32_t use_graph) { return done(M(m)->decode(steps, use_graph != 0)); }
-int kxm_prefill(void* m, const int32_t* tokens, int32_t n, int32_t pos0, float* logits) {
-  return done(M(m)->prefill(tokens, n, pos0, logits));
+int kxm_prefill(void* m, const int32_t* tokens, int32_t n, int32_t pos0, float* logits,
+                int32_t exact) {
+  return done(M(m)->prefill(tokens, n, pos0, logits, exact != 0));
 }
 int kxm_read_history(void* m, int32_t* out, int32_t n) { return done(M(m)->read_history(out, n)); }
 int kxm_read_state(void* m, int32_t* token, int32_t* pos) { return done(M(m)->read_state(token, pos)); }

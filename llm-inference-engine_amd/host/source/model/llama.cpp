@@ -1,5 +1,6 @@
 #include "model/llama.h"
 
+#include <cmath>
 #include <cstring>
 
 #include "kx_hip.h"
@@ -718,12 +719,10 @@ base::Status LlamaModel::decode(int32_t steps, bool use_graph) {
   return base::error::Success();
 }
 
-base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host) {
-  if (!tokens || n <= 0 || pos0 < 0 || pos0 + n > cfg_.seq_len)
-    return base::error::InvalidArgument("prompt does not fit in seq_len");
-  // The prompt is laid into the token history; each row then runs the fused step without
-  // sampling.  (The reference feeds the prompt one token per predict() as well,
-  // demo/main.cpp:18-41.)
+base::Status LlamaModel::prefill_sequential(const int32_t* tokens, int32_t n, int32_t pos0,
+                                            float* logits_host) {
+  // The prompt is laid into the token history; each row then runs the fused decode step without
+  // sampling -- exactly the reference's prompt phase, one token per step (demo/main.cpp:18-41).
   KX_RET(kx_stream_sync(hip_->stream));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
   KX_RET(kx_memcpy_h2d(pos_dev_, &pos0, 4, nullptr));
@@ -734,6 +733,84 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   KX_RET(kx_memcpy_d2h(&next, token_dev_, 4, nullptr));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0 + n, &next, 4, nullptr));
   if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)cfg_.vocab_size * 4, nullptr));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host,
+                                 bool exact) {
+  const TransformerConfig& c = cfg_;
+  if (!tokens || n <= 0 || pos0 < 0 || pos0 + n > c.seq_len)
+    return base::error::InvalidArgument("prompt does not fit in seq_len");
+  if (!quant_) return base::error::FunctionNotImplement("the fused path needs int8 weights");
+  if (exact || n < 4) return prefill_sequential(tokens, n, pos0, logits_host);
+
+  // Batched prompt: rows go through the MFMA GEMMs and the flash-attention kernel in chunks.
+  void* st = hip_->stream;
+  const int32_t ql = c.q_dim_local, kl = c.kv_dim_local, hl = c.hidden_local, dim = c.dim;
+  const int32_t chunk = n < kPrefillChunk ? n : kPrefillChunk;
+  // scratch: X, XN [chunk][dim]; Q, ATT [chunk][ql]; H13 [chunk][2hl]; HH [chunk][hl]
+  const size_t need = (size_t)chunk * (2 * (size_t)dim + 2 * (size_t)ql + 3 * (size_t)hl) * 4;
+  if (need > pf_bytes_) {
+    KX_RET(kx_stream_sync(st));
+    dev_free(pf_);
+    pf_bytes_ = 0;
+    void* p = nullptr;
+    KX_RET(kx_malloc(&p, need));
+    pf_ = static_cast<float*>(p);
+    pf_bytes_ = need;
+  }
+  float* X = pf_;
+  float* XN = X + (size_t)chunk * dim;
+  float* Q = XN + (size_t)chunk * dim;
+  float* ATT = Q + (size_t)chunk * ql;
+  float* H13 = ATT + (size_t)chunk * ql;
+  float* HH = H13 + (size_t)chunk * 2 * hl;
+  const int gs = c.group_size;
+  KX_RET(kx_stream_sync(st));
+  KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
+  float* kbase = static_cast<float*>(kv_->get_raw_buffer_k());
+  float* vbase = static_cast<float*>(kv_->get_raw_buffer_v());
+  const float* res = c.tp_rank == 0 ? X : nullptr;
+  int32_t rows = 0;
+  for (int32_t p0 = pos0; p0 < pos0 + n; p0 += rows) {
+    rows = pos0 + n - p0 < chunk ? pos0 + n - p0 : chunk;
+    KX_RET(kx_embedding_f32(history_dev_ + p0, rows, emb_, dim, c.vocab_size, X, st));
+    for (int32_t l = 0; l < c.layer_num; ++l) {
+      const LayerWeights& lw = layers_[l];
+      auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
+      float* krow = static_cast<float*>(k_ptr) + (size_t)p0 * kl;
+      float* vrow = static_cast<float*>(v_ptr) + (size_t)p0 * kl;
+      KX_RET(kx_rmsnorm_f32(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
+      KX_RET(kx_gemm_w8_f32_ex(XN, dim, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs, Q, ql,
+                               krow, kl, vrow, kl, ql, ql + kl, nullptr, 0, rows, dim,
+                               lw.qkv.rows, st));
+      KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
+      KX_RET(kx_flash_attention_f32(Q, kbase, vbase, ATT, rows, c.head_local, c.kv_head_local,
+                                    c.head_size, c.seq_len, p0 + rows - 1, l,
+                                    1.0f / std::sqrt((float)c.head_size), 1, hip_->attn_workspace,
+                                    hip_->attn_workspace_bytes, st));
+      KX_RET(kx_gemm_w8_f32_ex(ATT, ql, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs, X, dim,
+                               nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, ql, dim, st));
+      ST_RET(all_reduce(X, (size_t)rows * dim));
+      KX_RET(kx_rmsnorm_f32(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
+      KX_RET(kx_gemm_w8_f32_ex(XN, dim, static_cast<const int8_t*>(lw.w13.w), lw.w13.s, gs, H13,
+                               2 * hl, nullptr, 0, nullptr, 0, 2 * hl, 2 * hl, nullptr, 0, rows, dim,
+                               2 * hl, st));
+      KX_RET(kx_swiglu_rows_f32(H13, 2 * hl, hl, HH, hl, rows, st));
+      KX_RET(kx_gemm_w8_f32_ex(HH, hl, static_cast<const int8_t*>(lw.w2.w), lw.w2.s, gs, X, dim,
+                               nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, hl, dim, st));
+      ST_RET(all_reduce(X, (size_t)rows * dim));
+    }
+  }
+  // classifier on the last row only (cls_logits, llama3.cpp:790-799), then the greedy pick
+  const int32_t last_pos = pos0 + n - 1;
+  KX_RET(kx_memcpy_h2d(pos_dev_, &last_pos, 4, st));
+  ST_RET(gemv(cls_, KX_GEMV_PLAIN, X + (size_t)(rows - 1) * dim, final_norm_, logits_, nullptr,
+              nullptr, 0, 0, nullptr, st));
+  KX_RET(kx_decode_step_end(logits_, c.vocab_size, token_dev_, pos_dev_, history_dev_,
+                            c.seq_len + 1, step_ws_, kx_step_workspace_bytes(), st));
+  KX_RET(kx_stream_sync(st));
+  if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)c.vocab_size * 4, nullptr));
   return base::error::Success();
 }
 

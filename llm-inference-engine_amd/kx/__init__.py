@@ -58,6 +58,8 @@ SIGNATURES = {
     "kx_gemv_w8_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "kx_gemv_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_gemm_w8_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "kx_gemm_w8_f32_ex": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
+                                    C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
     "kx_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
@@ -70,6 +72,7 @@ SIGNATURES = {
     "kx_sin_cos_cache_f32": (C.c_int, [_i32, _i32, _f, _vp, _vp, _vp]),
     "kx_rope_f32": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "kx_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "kx_swiglu_rows_f32": (C.c_int, [_vp, C.c_int64, _i32, _vp, C.c_int64, _i32, _vp]),
     "kx_add_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "kx_embedding_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "kx_embedding_dpos_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -268,3 +271,14 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
                                        1 if is_causal else 0, ws.ptr, wsb, None),
           "kx_flash_attention_f32")
     return out.numpy(np.float32, q.shape)
+
+
+def gemm_w8(X, w, s, group_size=64):
+    K, M = w.shape
+    T = X.shape[0]
+    dx, dw, ds = Buf.from_numpy(X.astype(np.float32)), Buf.from_numpy(w.astype(np.int8)), \
+        Buf.from_numpy(s.astype(np.float32))
+    dy = Buf.zeros((T, K))
+    check(lib().kx_gemm_w8_f32(dx.ptr, dw.ptr, ds.ptr, group_size, dy.ptr, T, M, K, None),
+          "kx_gemm_w8_f32")
+    return dy.numpy(np.float32, (T, K))

@@ -59,7 +59,7 @@ def hlib():
         L.kxm_set_state.argtypes = [_vp, _i32, _i32]
         L.kxm_step_logits.argtypes = [_vp, _i32, _i32, _vp]
         L.kxm_decode.argtypes = [_vp, _i32, _i32]
-        L.kxm_prefill.argtypes = [_vp, _vp, _i32, _i32, _vp]
+        L.kxm_prefill.argtypes = [_vp, _vp, _i32, _i32, _vp, _i32]
         L.kxm_read_history.argtypes = [_vp, _vp, _i32]
         L.kxm_read_state.argtypes = [_vp, C.POINTER(_i32), C.POINTER(_i32)]
         L.kxm_read_kv.argtypes = [_vp, _i32, _i32, _vp, _vp]
@@ -161,10 +161,11 @@ class Model:
     def decode(self, steps, use_graph=True):
         hcheck(hlib().kxm_decode(self.h, int(steps), 1 if use_graph else 0), "kxm_decode")
 
-    def prefill(self, tokens, pos0=0):
+    def prefill(self, tokens, pos0=0, exact=False):
         t = np.ascontiguousarray(tokens, np.int32)
         out = np.empty(self.cfg.vocab_size, np.float32)
-        hcheck(hlib().kxm_prefill(self.h, _p(t), t.size, int(pos0), _p(out)), "kxm_prefill")
+        hcheck(hlib().kxm_prefill(self.h, _p(t), t.size, int(pos0), _p(out), 1 if exact else 0),
+               "kxm_prefill")
         return out
 
     def history(self, n):

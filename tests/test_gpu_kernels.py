@@ -320,3 +320,106 @@ def test_streams_events_graph_replay():
     assert e0.elapsed_ms(e1) >= 0
     assert np.all(np.abs(dy.numpy() - kxo.gemv_w8(x, w, s, GS)) <= 1e-5 * w8_abs_sum(x, w, s))
     kx.check(L.kx_graph_destroy(ge))
+
+
+# ------------------------------- prefill: W8A16 MFMA GEMM ----------------------------------------
+# Tolerance: the only deviation from the fp32 formula is the fp16 rounding of X (relative 2^-11
+# per element), so |err| <= 2^-11 * sum|terms| is a hard bound; random signs land far below it.
+@pytest.mark.parametrize("T,K,M", [(4, 128, 64), (37, 200, 128), (128, 128, 256), (130, 384, 512),
+                                   (300, 1000, 1024), (64, 6144, 4096)])
+def test_gemm_w8_vs_oracle(T, K, M):
+    rng = np.random.default_rng(T * 7 + K)
+    _, w, s = rand_w8(rng, K, M)
+    X = rng.standard_normal((T, M)).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    got = kx.gemm_w8(X, w, s, GS)
+    sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
+    absum = np.abs(X.astype(np.float64)) @ sd.T
+    err = np.abs(got - want)
+    assert np.all(err <= 2.0 ** -11 * absum + 1e-7)
+    assert np.sqrt((err ** 2).mean()) <= 1e-4 * np.sqrt((absum ** 2).mean())
+
+
+def test_gemm_w8_small_T_and_odd_group_fall_back_to_gemv_rows():
+    rng = np.random.default_rng(2)
+    x, w, s = rand_w8(rng, 96, 192)
+    X = rng.standard_normal((3, 192)).astype(np.float32)
+    got = kx.gemm_w8(X, w, s, GS)  # T < 4: row-wise GEMV, fp32 exact path
+    want = kxo.gemm_w8(X, w, s, GS)
+    for t in range(3):
+        assert np.all(np.abs(got[t] - want[t]) <= 1e-5 * w8_abs_sum(X[t], w, s))
+
+
+def test_gemm_w8_ex_routing_and_residual():
+    rng = np.random.default_rng(3)
+    T, dim, kvd, S = 70, 256, 128, 96
+    K = dim + 2 * kvd
+    _, w, s = rand_w8(rng, K, dim)
+    X = rng.standard_normal((T, dim)).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    dx, dw, ds = map(kx.Buf.from_numpy, (X, w, s))
+    q = kx.Buf.zeros((T, dim))
+    kc, vc = kx.Buf.zeros((S, kvd)), kx.Buf.zeros((S, kvd))
+    pos0 = 11  # k/v rows land in cache rows pos0 .. pos0+T-1
+    kx.check(kx.lib().kx_gemm_w8_f32_ex(dx.ptr, dim, dw.ptr, ds.ptr, GS, q.ptr, dim,
+                                        kc.at(pos0 * kvd * 4), kvd, vc.at(pos0 * kvd * 4), kvd, dim,
+                                        dim + kvd, None, 0, T, dim, K, None))
+    tol = 2.0 ** -11 * (np.abs(X.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(
+        K, dim) * np.abs(w.astype(np.float64))).T) + 1e-7
+    assert np.all(np.abs(q.numpy() - want[:, :dim]) <= tol[:, :dim])
+    kcn, vcn = kc.numpy(), vc.numpy()
+    assert np.all(np.abs(kcn[pos0:pos0 + T] - want[:, dim:dim + kvd]) <= tol[:, dim:dim + kvd])
+    assert np.all(np.abs(vcn[pos0:pos0 + T] - want[:, dim + kvd:]) <= tol[:, dim + kvd:])
+    assert np.all(kcn[:pos0] == 0) and np.all(kcn[pos0 + T:] == 0)
+    # residual in place
+    R = rng.standard_normal((T, dim)).astype(np.float32)
+    y = kx.Buf.from_numpy(R)
+    kx.check(kx.lib().kx_gemm_w8_f32_ex(dx.ptr, dim, dw.ptr, ds.ptr, GS, y.ptr, dim, None, 0, None,
+                                        0, dim, dim, y.ptr, dim, T, dim, dim, None))
+    assert np.all(np.abs(y.numpy() - (want[:, :dim] + R)) <= tol[:, :dim] + 1e-6)
+
+
+# ------------------------------- prefill: MFMA flash attention -------------------------------------
+# Q*scale, K, V and the probabilities are rounded to fp16 for the matrix instructions
+# (softmax, accumulation and the output are fp32): stated tolerance 3e-3 absolute on N(0,1) data.
+def test_flash_attention_golden(golden):
+    g = golden("g5_attention.npz")
+    ran = 0
+    for name, meta, q, kc, vc, want in _attn_cases(g):
+        H, KVH, hs, S, pos, Tq, L, layer = [int(v) for v in meta[:8]]
+        if Tq == 1:
+            continue
+        got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, layer)
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-3, err_msg=name)
+        ran += 1
+    assert ran >= 4  # includes the reference test's own inputs (head size 8: row-wise path)
+
+
+@pytest.mark.parametrize("H,KVH,hs,S,pos,Tq,causal", [
+    (8, 2, 64, 300, 255, 256, True), (8, 2, 128, 300, 299, 130, True), (4, 4, 64, 200, 150, 33, True),
+    (14, 2, 128, 160, 159, 160, True), (16, 2, 128, 128, 100, 64, True), (6, 2, 64, 100, 99, 50, False),
+    (4, 2, 32, 70, 69, 70, True)])
+def test_flash_attention_vs_oracle(H, KVH, hs, S, pos, Tq, causal):
+    rng = np.random.default_rng(H * 31 + Tq)
+    L, layer = 2, 1
+    kc = rng.standard_normal((L, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((L, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal((Tq, H, hs)).astype(np.float32)
+    want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, layer, is_causal=causal, threads=8)
+    got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, layer, is_causal=causal)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
+    assert np.sqrt(((got - want) ** 2).mean()) <= 4e-4
+
+
+def test_flash_attention_forced_rescale_and_last_row_equals_decode():
+    rng = np.random.default_rng(8)
+    H, KVH, hs, S, pos, Tq = 8, 2, 128, 320, 319, 320
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32) * 0.2
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal((Tq, H, hs)).astype(np.float32)
+    kc[0, 200, :hs] = q[250, 0] * 2.0  # late spike: the running max jumps at key tile 3
+    want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, 0, threads=8)
+    got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
+    last = kx.mha_decode(q[-1].reshape(-1), kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(got[-1], last, rtol=0, atol=3e-3)
