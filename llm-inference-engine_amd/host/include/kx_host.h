@@ -27,6 +27,10 @@ void kxm_destroy(void* model);
 int kxm_init_synthetic(void* model, uint64_t seed);
 int kxm_load_blob(void* model, const void* blob, size_t bytes);
 int kxm_read_weight(void* model, const char* name, int32_t layer, void* host_out, size_t bytes);
+/* Tensor-parallel shard plan (pure host logic, callable without a GPU): {row0, rows, col0, cols}
+ * for wq, wk, wv, wo, w1, w2, w3 in that order; -1 when the geometry does not divide. */
+int kxm_shard_plan(int32_t dim, int32_t hidden_dim, int32_t head_num, int32_t kv_head_num,
+                   int32_t tp_size, int32_t tp_rank, int32_t* slices28, int32_t* carries_residual);
 int kxm_comm_unique_id(void* id128);
 int kxm_init_comm(void* model, const void* id128);
 int kxm_forward_layers(void* model, int32_t token, int32_t pos, float* logits_host);

@@ -30,6 +30,7 @@
 #include "op/matmul.h"
 #include "op/mha.h"
 #include "op/support_layers.h"
+#include "model/shard_plan.h"
 
 namespace model {
 
@@ -57,6 +58,7 @@ struct TransformerConfig {
   int32_t kv_dim = 0, kv_mul = 0, head_size = 0;
   // per-rank sizes under tensor parallelism
   int32_t q_dim_local = 0, kv_dim_local = 0, hidden_local = 0, head_local = 0, kv_head_local = 0;
+  ShardPlan plan;
   base::Status finalize();
 };
 
@@ -141,6 +143,7 @@ class LlamaModel {
 
   TransformerConfig cfg_;
   bool quant_ = false;
+  bool comm_ready_ = false;
   std::shared_ptr<kernel::CudaConfig> hip_;
   std::vector<LayerWeights> layers_;
   Linear cls_;

@@ -26,7 +26,9 @@ Status RcclHandler::CreateUniqueId(CommUniqueId* id) {
 Status RcclHandler::Init(int32_t rank, int32_t world_size, const CommUniqueId* id) {
   rank_ = rank;
   world_size_ = world_size;
-  if (world_size_ <= 1) return error::Success();  // nccl_handler.cpp:27-29
+  // One rank and no id: nothing to set up (nccl_handler.cpp:27-29).  One rank WITH an id builds a
+  // real single-rank communicator, so the collectives can be exercised on one GPU.
+  if (world_size_ <= 1 && !id) return error::Success();
   if (!id) return error::InvalidArgument("world_size > 1 needs the unique id made on rank 0");
   if (comm_) {
     kx_comm_destroy(comm_);
@@ -37,7 +39,7 @@ Status RcclHandler::Init(int32_t rank, int32_t world_size, const CommUniqueId* i
 
 Status RcclHandler::AllReduce(const void* sendbuff, void* recvbuff, size_t count, DataType datatype,
                               void* stream) {
-  if (world_size_ <= 1) return error::Success();
+  if (world_size_ <= 1 && !comm_) return error::Success();
   if (datatype != DataType::kDataTypeFp32)
     return error::InvalidArgument("Unsupported data type for AllReduce");
   return from_rc(kx_comm_allreduce_sum_f32(comm_, static_cast<const float*>(sendbuff),
@@ -47,7 +49,7 @@ Status RcclHandler::AllReduce(const void* sendbuff, void* recvbuff, size_t count
 
 Status RcclHandler::Broadcast(const void* sendbuff, void* recvbuff, size_t count, DataType datatype,
                               int32_t root, void* stream) {
-  if (world_size_ <= 1) return error::Success();
+  if (world_size_ <= 1 && !comm_) return error::Success();
   if (datatype != DataType::kDataTypeFp32)
     return error::InvalidArgument("Unsupported data type for Broadcast");
   return from_rc(kx_comm_broadcast_f32(comm_, static_cast<const float*>(sendbuff),
@@ -57,7 +59,7 @@ Status RcclHandler::Broadcast(const void* sendbuff, void* recvbuff, size_t count
 
 Status RcclHandler::AllGather(const void* sendbuff, void* recvbuff, size_t send_count,
                               DataType datatype, void* stream) {
-  if (world_size_ <= 1) return error::Success();
+  if (world_size_ <= 1 && !comm_) return error::Success();
   if (datatype != DataType::kDataTypeFp32)
     return error::InvalidArgument("Unsupported data type for AllGather");
   return from_rc(kx_comm_allgather_f32(comm_, static_cast<const float*>(sendbuff),

@@ -52,6 +52,22 @@ int kxm_load_blob(void* m, const void* blob, size_t bytes) { return done(M(m)->l
 int kxm_read_weight(void* m, const char* name, int32_t layer, void* out, size_t bytes) {
   return done(M(m)->read_weight(name, layer, out, bytes));
 }
+int kxm_shard_plan(int32_t dim, int32_t hidden_dim, int32_t head_num, int32_t kv_head_num,
+                   int32_t tp_size, int32_t tp_rank, int32_t* slices28, int32_t* carries_residual) {
+  model::ShardPlan p;
+  if (!slices28 || !model::make_shard_plan(dim, hidden_dim, head_num, kv_head_num, tp_size, tp_rank, &p))
+    return -1;
+  const model::ShardSlice* all[7] = {&p.wq, &p.wk, &p.wv, &p.wo, &p.w1, &p.w2, &p.w3};
+  for (int i = 0; i < 7; ++i) {
+    slices28[4 * i + 0] = all[i]->row0;
+    slices28[4 * i + 1] = all[i]->rows;
+    slices28[4 * i + 2] = all[i]->col0;
+    slices28[4 * i + 3] = all[i]->cols;
+  }
+  if (carries_residual) *carries_residual = p.carries_residual ? 1 : 0;
+  return 0;
+}
+
 int kxm_comm_unique_id(void* id128) {
   base::CommUniqueId id;
   base::Status s = base::RcclHandler::CreateUniqueId(&id);

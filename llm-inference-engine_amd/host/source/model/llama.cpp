@@ -63,13 +63,13 @@ base::Status TransformerConfig::finalize() {
   kv_mul = head_num / kv_head_num;            // model.cpp:133
   if (tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size)
     return base::error::InvalidArgument("bad tensor-parallel rank/size");
-  if (head_num % tp_size || kv_head_num % tp_size || hidden_dim % tp_size)
+  if (!make_shard_plan(dim, hidden_dim, head_num, kv_head_num, tp_size, tp_rank, &plan))
     return base::error::InvalidArgument("heads / kv heads / hidden_dim must divide by tp_size");
-  head_local = head_num / tp_size;
-  kv_head_local = kv_head_num / tp_size;
-  q_dim_local = head_local * head_size;
-  kv_dim_local = kv_head_local * head_size;
-  hidden_local = hidden_dim / tp_size;
+  head_local = plan.head_local;
+  kv_head_local = plan.kv_head_local;
+  q_dim_local = plan.q_dim_local;
+  kv_dim_local = plan.kv_dim_local;
+  hidden_local = plan.hidden_local;
   if (group_size > 0) {
     // quant groups run along the input dimension; row-parallel shards must cut on group borders
     if (dim % group_size || hidden_dim % group_size || q_dim_local % group_size ||
@@ -213,24 +213,23 @@ base::Status LlamaModel::fill_linear_rows(Linear& l, int32_t row_off, int32_t ro
 
 base::Status LlamaModel::init_synthetic(uint64_t seed) {
   const TransformerConfig& c = cfg_;
-  const int r = c.tp_rank;
+  const ShardPlan& sp = c.plan;
   void* st = hip_->stream;
   std::vector<float> ones(c.dim, 1.0f);
   for (int l = 0; l < c.layer_num; ++l) {
     LayerWeights& lw = layers_[l];
     auto sd = [&](int m) { return seed * 1000003ull + (uint64_t)l * 64 + m; };
-    // column-parallel: this rank's rows of the global matrices
-    ST_RET(fill_linear_rows(lw.qkv, 0, c.q_dim_local, c.dim, (int64_t)r * c.q_dim_local, 0, sd(0)));
-    ST_RET(fill_linear_rows(lw.qkv, c.q_dim_local, c.kv_dim_local, c.dim,
-                            (int64_t)r * c.kv_dim_local, 0, sd(1)));
-    ST_RET(fill_linear_rows(lw.qkv, c.q_dim_local + c.kv_dim_local, c.kv_dim_local, c.dim,
-                            (int64_t)r * c.kv_dim_local, 0, sd(2)));
-    // row-parallel: this rank's columns
-    ST_RET(fill_linear_rows(lw.wo, 0, c.dim, c.dim, 0, (int64_t)r * c.q_dim_local, sd(3)));
-    ST_RET(fill_linear_rows(lw.w13, 0, c.hidden_local, c.dim, (int64_t)r * c.hidden_local, 0, sd(4)));
-    ST_RET(fill_linear_rows(lw.w13, c.hidden_local, c.hidden_local, c.dim,
-                            (int64_t)r * c.hidden_local, 0, sd(6)));
-    ST_RET(fill_linear_rows(lw.w2, 0, c.dim, c.hidden_dim, 0, (int64_t)r * c.hidden_local, sd(5)));
+    // every shard is a slice of one global tensor: element values depend on global indices only
+    auto fill = [&](Linear& lin, int32_t dst_row, const ShardSlice& sl, int64_t g_ld, int m) {
+      return fill_linear_rows(lin, dst_row, sl.rows, g_ld, sl.row0, sl.col0, sd(m));
+    };
+    ST_RET(fill(lw.qkv, 0, sp.wq, c.dim, 0));
+    ST_RET(fill(lw.qkv, c.q_dim_local, sp.wk, c.dim, 1));
+    ST_RET(fill(lw.qkv, c.q_dim_local + c.kv_dim_local, sp.wv, c.dim, 2));
+    ST_RET(fill(lw.wo, 0, sp.wo, c.dim, 3));
+    ST_RET(fill(lw.w13, 0, sp.w1, c.dim, 4));
+    ST_RET(fill(lw.w13, c.hidden_local, sp.w3, c.dim, 6));
+    ST_RET(fill(lw.w2, 0, sp.w2, c.hidden_dim, 5));
     KX_RET(kx_memcpy_h2d(lw.attn_norm, ones.data(), c.dim * sizeof(float), nullptr));
     KX_RET(kx_memcpy_h2d(lw.ffn_norm, ones.data(), c.dim * sizeof(float), nullptr));
   }
@@ -292,7 +291,7 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
   }
   const size_t dim = c.dim, hid = c.hidden_dim, L = c.layer_num, V = c.vocab_size;
   const size_t kvd = c.kv_dim;
-  const int r = c.tp_rank;
+  const ShardPlan& sp = c.plan;
   const uint8_t* p = static_cast<const uint8_t*>(blob) + hdr;
   const uint8_t* end = static_cast<const uint8_t*>(blob) + bytes;
   const size_t esz = quant_ ? 1 : 4;
@@ -321,26 +320,31 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
   const uint8_t* cls_w = nullptr;
   const float* cls_s = nullptr;
   const int32_t ql = c.q_dim_local, kl = c.kv_dim_local, hl = c.hidden_local;
+  auto up = [&](Linear& lin, int32_t dst_row, const uint8_t* w, const float* s, size_t g_rows,
+                size_t g_cols, const ShardSlice& sl) {
+    return upload_matrix(lin, dst_row, w, s, (int32_t)g_rows, (int32_t)g_cols, sl.row0, sl.rows,
+                         sl.col0, sl.cols);
+  };
   auto up_q = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].qkv, 0, w, s, dim, dim, r * ql, ql, 0, dim);
+    return up(layers_[l].qkv, 0, w, s, dim, dim, sp.wq);
   };
   auto up_k = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].qkv, ql, w, s, kvd, dim, r * kl, kl, 0, dim);
+    return up(layers_[l].qkv, ql, w, s, kvd, dim, sp.wk);
   };
   auto up_v = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].qkv, ql + kl, w, s, kvd, dim, r * kl, kl, 0, dim);
+    return up(layers_[l].qkv, ql + kl, w, s, kvd, dim, sp.wv);
   };
   auto up_o = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].wo, 0, w, s, dim, dim, 0, dim, r * ql, ql);
+    return up(layers_[l].wo, 0, w, s, dim, dim, sp.wo);
   };
   auto up_1 = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].w13, 0, w, s, hid, dim, r * hl, hl, 0, dim);
+    return up(layers_[l].w13, 0, w, s, hid, dim, sp.w1);
   };
   auto up_2 = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].w2, 0, w, s, dim, hid, 0, dim, r * hl, hl);
+    return up(layers_[l].w2, 0, w, s, dim, hid, sp.w2);
   };
   auto up_3 = [&](size_t l, const uint8_t* w, const float* s) {
-    return upload_matrix(layers_[l].w13, hl, w, s, hid, dim, r * hl, hl, 0, dim);
+    return up(layers_[l].w13, hl, w, s, hid, dim, sp.w3);
   };
   if (!quant_) {
     // tools/export_llama.py:96-127
@@ -435,7 +439,11 @@ base::Status LlamaModel::read_weight(const std::string& name, int32_t layer, voi
 }
 
 base::Status LlamaModel::init_comm(const base::CommUniqueId* id) {
-  return base::RcclHandler::get_instance()->Init(cfg_.tp_rank, cfg_.tp_size, id);
+  ST_RET(base::RcclHandler::get_instance()->Init(cfg_.tp_rank, cfg_.tp_size, id));
+  // With a communicator of one rank the all-reduces still run (as identities): the collective,
+  // its side stream and its events are then exercised, graph capture included, on a single GPU.
+  comm_ready_ = cfg_.tp_size > 1 || id != nullptr;
+  return base::error::Success();
 }
 
 double LlamaModel::linear_weight_bytes_per_token() const {
@@ -632,7 +640,8 @@ base::Status LlamaModel::gemv(const Linear& l, int mode, const float* x, const f
 }
 
 base::Status LlamaModel::all_reduce(float* buf, size_t count) {
-  if (cfg_.tp_size <= 1) return base::error::Success();
+  if (cfg_.tp_size <= 1 && !comm_ready_) return base::error::Success();
+  if (!comm_ready_) return base::error::InternalError("tensor-parallel model without init_comm()");
   auto comm = base::RcclHandler::get_instance();
   // all-reduce on the side stream between two reused events (matmul.cpp:93-116)
   KX_RET(kx_event_record(hip_->compute_done, hip_->stream));
@@ -658,7 +667,7 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
                                   c.seq_len - 1, c.head_local, c.kv_mul, c.head_size, kl, c.seq_len,
                                   l, hip_->attn_workspace, hip_->attn_workspace_bytes, st));
     // row-parallel: every rank holds a partial sum; rank 0 carries the residual into the sum
-    const float* res = c.tp_rank == 0 ? x_ : nullptr;
+    const float* res = c.plan.carries_residual ? x_ : nullptr;
     ST_RET(gemv(lw.wo, KX_GEMV_PLAIN, att_, nullptr, x_, nullptr, nullptr, 0, 0, res, st));
     ST_RET(all_reduce(x_, c.dim));
     ST_RET(gemv(lw.w13, KX_GEMV_GATE_UP, x_, lw.ffn_norm, h_, nullptr, nullptr, 0, 0, nullptr, st));
@@ -770,7 +779,7 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
   float* kbase = static_cast<float*>(kv_->get_raw_buffer_k());
   float* vbase = static_cast<float*>(kv_->get_raw_buffer_v());
-  const float* res = c.tp_rank == 0 ? X : nullptr;
+  const float* res = c.plan.carries_residual ? X : nullptr;
   int32_t rows = 0;
   for (int32_t p0 = pos0; p0 < pos0 + n; p0 += rows) {
     rows = pos0 + n - p0 < chunk ? pos0 + n - p0 : chunk;

@@ -200,6 +200,25 @@ class Model:
         return hlib().kxm_stream(self.h)
 
 
+SHARD_NAMES = ("wq", "wk", "wv", "wo", "w1", "w2", "w3")
+
+
+def shard_plan(dim, hidden_dim, head_num, kv_head_num, tp_size, tp_rank):
+    """The rank's slice of every layer matrix as {name: (row0, rows, col0, cols)} plus whether
+    the rank carries the residual.  Host logic of the library itself; needs no GPU."""
+    out = (C.c_int32 * 28)()
+    res = C.c_int32(0)
+    L = hlib()
+    L.kxm_shard_plan.restype = C.c_int
+    L.kxm_shard_plan.argtypes = [_i32] * 6 + [_vp, _vp]
+    rc = L.kxm_shard_plan(dim, hidden_dim, head_num, kv_head_num, tp_size, tp_rank, out,
+                          C.byref(res))
+    if rc != 0:
+        raise ValueError("geometry does not divide over tp_size ranks")
+    plan = {n: tuple(out[4 * i:4 * i + 4]) for i, n in enumerate(SHARD_NAMES)}
+    return plan, bool(res.value)
+
+
 def comm_unique_id():
     buf = np.zeros(128, np.uint8)
     hcheck(hlib().kxm_comm_unique_id(_p(buf)), "kxm_comm_unique_id")

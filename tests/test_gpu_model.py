@@ -234,6 +234,44 @@ def test_batched_prefill_vs_oracle_rows(shape, n):
         assert mm.history(n + 1)[n] == tok
 
 
+def test_tp_shards_are_slices_of_the_unsharded_weights():
+    # column-parallel rows / row-parallel columns as the shard plan says, for synthetic weights
+    shape = dict(dim=512, hidden_dim=1024, layer_num=1, head_num=8, kv_head_num=2, vocab_size=256,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    full = host.Model(seq_len=16, group_size=GS, **shape)
+    full.init_synthetic(5)
+    for r in range(2):
+        m = host.Model(seq_len=16, group_size=GS, tp_size=2, tp_rank=r, **shape)
+        m.init_synthetic(5)
+        plan, _ = host.shard_plan(512, 1024, 8, 2, 2, r)
+        for name, (r0, rows, c0, cols) in plan.items():
+            np.testing.assert_array_equal(m.read_weight(name),
+                                          full.read_weight(name)[r0:r0 + rows, c0:c0 + cols])
+            sf = full.read_weight(name + "_s")
+            sf = sf.reshape(full.read_weight(name).shape[0], -1)
+            np.testing.assert_array_equal(m.read_weight(name + "_s").reshape(rows, -1),
+                                          sf[r0:r0 + rows, c0 // GS:(c0 + cols) // GS])
+
+
+def test_single_rank_communicator_runs_the_allreduce_path():
+    # A one-rank RCCL communicator: the all-reduces after Wo and W2 (side stream, two events) run
+    # as identities, eagerly, under graph capture/replay and in the batched prompt pass.
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    toks = np.random.default_rng(1).integers(0, 1000, 24).astype(np.int32)
+    runs = []
+    for with_comm in (False, True):
+        m = host.Model(seq_len=64, group_size=GS, **shape)
+        m.init_synthetic(9)
+        if with_comm:
+            m.init_comm(host.comm_unique_id())
+        last = m.prefill(toks)
+        m.decode(12, use_graph=True)
+        runs.append((last, m.history(len(toks) + 13)))
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+
+
 def test_fused_path_refuses_fp32_weights():
     m = host.Model(seq_len=8, group_size=0, **TINY)
     m.init_synthetic(1)
