@@ -157,9 +157,13 @@ int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, 
  * (cuda/mha_kernel.cu:50-127) and mha_kernel (cpu/mha_kernel.cpp:5-61) behind MHAKernel
  * (kernels_interface.h:22-28): for each head h, softmax over t<=pos of
  * (q_h . K[layer][t][(h/kv_mul)*hs..]) / sqrt(hs), then the weighted sum of V rows.
- * `workspace` holds split-KV partials; kx_attn_workspace_bytes() sizes it.  The reference's
- * score tensor [head_num][seq_len] may be passed as the workspace when it is large enough;
- * the probabilities the reference leaves there are not reproduced (nothing reads them,
+ * `workspace` holds, in its first 16 KiB, one arrival counter per kv head (256 bytes apart), then the
+ * split-KV partials; kx_attn_workspace_bytes() sizes it.  ZERO IT ONCE after allocating it: every
+ * launch returns the counters to zero, so no per-call clearing is needed.  Launches that share a
+ * workspace must not overlap in time (one stream, or one workspace per stream).  Head sizes other
+ * than 32/64/128 fall back to a kernel that needs 16384 + head_num*seq_len*4 bytes instead.  The
+ * reference's score tensor [head_num][seq_len] plays this role there (llama3.cpp:523-525); the
+ * probabilities the reference leaves in it are not reproduced (nothing reads them,
  * llama3.cpp:724-733). */
 size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size);
 int kx_mha_decode_f32(const float* query, const float* key_cache, const float* value_cache,

@@ -12,7 +12,8 @@
 // v_mfma_f32_16x16x4_f32 (an fp32 fma chain, bit-compatible with VALU fmaf): the score tile
 // comes out with the key index on the register axis and the head on the lane, which is
 // already the B-operand layout of the P.V product, so probabilities never cross lanes.
-// Softmax is online (running max / sum); split results are merged by a second tiny kernel.
+// Softmax is online (running max / sum); the workgroup that finishes last for a kv head (an
+// arrival ticket in the workspace) merges the split results, so one launch does it all.
 #include <math.h>
 
 #include "kx_common.hpp"
@@ -20,22 +21,76 @@
 namespace kx {
 
 constexpr int kAttnWaves = 4;
-constexpr int kMaxSplits = 64;
+constexpr int kMaxSplits = 128;
+// Head of the workspace: one arrival ticket per kv head.  Zero before the first launch; every
+// launch leaves the tickets at zero again (atomicInc wraps at the launch's split count).
+// Tickets sit 256 bytes apart: device-scope atomics on one cache line serialise.
+constexpr size_t kTicketStride = 256;
+constexpr int kMaxTickets = 64;
+constexpr size_t kTicketBytes = kTicketStride * kMaxTickets;
 
-// workspace per (head, split): m, l, then O[hs]
-__host__ __device__ inline size_t attn_ws_stride(int hs) { return (size_t)hs + 2; }
+// workspace record per (head, split): O[hs], then m, l and two pad words (16-byte aligned rows)
+__host__ __device__ inline size_t attn_ws_stride(int hs) { return (size_t)hs + 4; }
+
+// split geometry shared by host and device: whole groups of kAttnWaves tiles per split, so every
+// wave of a workgroup gets the same number of 16-key tiles
+__host__ __device__ inline int attn_tiles_per_split(int ntiles, int grid_splits) {
+  const int tps = (ntiles + grid_splits - 1) / grid_splits;
+  return (tps + kAttnWaves - 1) / kAttnWaves * kAttnWaves;
+}
+
+// Device-scope relaxed accesses: write-through stores / cache-bypassing loads.
+__device__ __forceinline__ void st_device(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_device(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int HS>
-__global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
+struct AttnTile {
+  static constexpr int NJ = HS / 16;
+  static constexpr int NH = HS >= 64 ? HS / 64 : 1;
+  f32x4 k[NJ];
+  f32x4 v[4][NH];
+};
+
+template <int HS>
+__device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const float* __restrict__ kbase,
+                                               const float* __restrict__ vbase, int key0, int last,
+                                               int kv_dim, int n, int g) {
+  constexpr int NJ = AttnTile<HS>::NJ, NH = AttnTile<HS>::NH;
+  constexpr int DLV = HS >= 64 ? 16 : HS / 4;  // dim-lanes that carry data
+  // K: lane (key n, g) loads K[key][16j+4g .. +4)
+  const float* kr = kbase + (size_t)min(key0 + n, last) * kv_dim + 4 * g;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) T.k[j] = *reinterpret_cast<const f32x4*>(kr + 16 * j);
+  // V: lane (dim-lane n, g) loads V[key0+4g+r][64h+4n .. +4)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float* vr = vbase + (size_t)min(key0 + 4 * g + r, last) * kv_dim + 4 * n;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      T.v[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n < DLV) T.v[r][h] = *reinterpret_cast<const f32x4*>(vr + 64 * h);
+    }
+  }
+}
+
+// PREFETCH: a wave with several tiles requests the next one before it consumes the current one
+// (costs a second set of tile registers; pointless when every wave has a single tile).
+template <int HS, bool PREFETCH>
+__global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
-    float* __restrict__ out, float* __restrict__ ws, int last_val, const int32_t* __restrict__ pos_dev,
-    int kv_mul, int kv_dim, float scale) {
-  constexpr int NJ = HS / 16;                 // float4 K loads per lane per tile
-  constexpr int NH = HS >= 64 ? HS / 64 : 1;  // 64-dim halves of the output
-  constexpr int DLV = HS >= 64 ? 16 : HS / 4; // dim-lanes that carry data
+    float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
+    const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale) {
+  constexpr int NJ = AttnTile<HS>::NJ;  // float4 K loads per lane per tile
+  constexpr int NH = AttnTile<HS>::NH;  // 64-dim halves of the output
   __shared__ float sm_m[kAttnWaves][16];
   __shared__ float sm_l[kAttnWaves][16];
   __shared__ float sm_o[kAttnWaves][16][HS];
+  __shared__ float sm_sf[kAttnWaves * kMaxSplits];  // final merge: split weights, one set per wave
+  __shared__ int sm_last;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -44,11 +99,17 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
   // the grid is then sized for the longest context and surplus splits leave at once.
   const int last = pos_dev ? *pos_dev : last_val;
   const int ntiles = (last >> 4) + 1;
-  const int tiles_per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int tiles_per_split = attn_tiles_per_split(ntiles, (int)gridDim.y);
   const int nsplit = (ntiles + tiles_per_split - 1) / tiles_per_split;
   if (split >= nsplit) return;
   const float* kbase = kc + (size_t)kvh * HS;
   const float* vbase = vc + (size_t)kvh * HS;
+
+  const int t_begin = split * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, ntiles);
+  int t = t_begin + wave;
+  AttnTile<HS> cur;
+  if (t < t_end) attn_load_tile<HS>(cur, kbase, vbase, t << 4, last, kv_dim, n, g);
 
   // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e]
   float qf[NJ][4];
@@ -67,39 +128,29 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     for (int e = 0; e < 4; ++e) o[h][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int t_begin = split * tiles_per_split;
-  const int t_end = min(t_begin + tiles_per_split, ntiles);
-  for (int t = t_begin + wave; t < t_end; t += kAttnWaves) {
+  for (; t < t_end; t += kAttnWaves) {
     const int key0 = t << 4;
-    // ---- K tile: lane (key n, g) loads K[key][16j+4g .. +4) ----
-    f32x4 kf[NJ];
-    {
-      const float* kr = kbase + (size_t)min(key0 + n, last) * kv_dim + 4 * g;
+    // the wave's next tile is requested before this one is consumed
+    AttnTile<HS> nxt;
+    const bool more = t + kAttnWaves < t_end;
+    if (PREFETCH && more)
+      attn_load_tile<HS>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
+    // ---- S^T[key][head] = K . Q^T (two independent accumulation chains) ----
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kr + 16 * j);
-    }
-    // ---- V tile: lane (dim-lane n, g) loads V[key0+4g+r][64h+4n .. +4) ----
-    f32x4 vf[4][NH];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* vr = vbase + (size_t)min(key0 + 4 * g + r, last) * kv_dim + 4 * n;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        vf[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n < DLV) vf[r][h] = *reinterpret_cast<const f32x4*>(vr + 64 * h);
-      }
-    }
-    // ---- S^T[key][head] = K . Q^T ----
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].x, qf[j][0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].y, qf[j][1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].z, qf[j][2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].w, qf[j][3], s, 0, 0, 0);
+    for (int j = 0; j < NJ; j += 2) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j].x, qf[j][0], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j + 1].x, qf[j + 1][0], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j].y, qf[j][1], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j + 1].y, qf[j + 1][1], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j].z, qf[j][2], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j + 1].z, qf[j + 1][2], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j].w, qf[j][3], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.k[j + 1].w, qf[j + 1][3], s1, 0, 0, 0);
     }
     // lane (head n, g) now holds scores of keys key0+4g+r, r=0..3
-    float sv[4] = {s.x * scale, s.y * scale, s.z * scale, s.w * scale};
+    float sv[4] = {(s0.x + s1.x) * scale, (s0.y + s1.y) * scale, (s0.z + s1.z) * scale,
+                   (s0.w + s1.w) * scale};
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (key0 + 4 * g + r > last) sv[r] = -INFINITY;
@@ -123,11 +174,15 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        o[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][h].x, p[r], o[h][0], 0, 0, 0);
-        o[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][h].y, p[r], o[h][1], 0, 0, 0);
-        o[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][h].z, p[r], o[h][2], 0, 0, 0);
-        o[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][h].w, p[r], o[h][3], 0, 0, 0);
+        o[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[r][h].x, p[r], o[h][0], 0, 0, 0);
+        o[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[r][h].y, p[r], o[h][1], 0, 0, 0);
+        o[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[r][h].z, p[r], o[h][2], 0, 0, 0);
+        o[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[r][h].w, p[r], o[h][3], 0, 0, 0);
       }
+    if (more) {
+      if (PREFETCH) cur = nxt;
+      else attn_load_tile<HS>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
+    }
   }
 
   // ---- wave result -> LDS.  lane (head n, g'): o[h][e][r'] = O[head][64h + 4(4g'+r') + e] ----
@@ -161,7 +216,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     float L = 0.f, O = 0.f;
 #pragma unroll
     for (int w = 0; w < kAttnWaves; ++w) {
-      const float f = expf(sm_m[w][head] - M);
+      // a wave without tiles carries m = -inf, l = 0, o = 0
+      const float f = sm_m[w][head] == -INFINITY ? 0.f : expf(sm_m[w][head] - M);
       L += sm_l[w][head] * f;
       O += sm_o[w][head][d] * f;
     }
@@ -169,65 +225,96 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attn_decode_kernel(
     if (nsplit == 1) {
       out[(size_t)hq * HS + d] = O / L;
     } else {
+      // write-through (device-scope) stores: visible to the merging workgroup on any XCD without
+      // a cache write-back
       float* dst = ws + ((size_t)hq * gridDim.y + split) * attn_ws_stride(HS);
       if (d == 0) {
-        dst[0] = M;
-        dst[1] = L;
+        st_device(dst + HS, M);
+        st_device(dst + HS + 1, L);
       }
-      dst[2 + d] = O;
+      st_device(dst + d, O);
     }
   }
-}
+  if (nsplit == 1) return;
 
-// out[h][d] = sum_s O_s[d] e^{m_s-M} / sum_s l_s e^{m_s-M}
-// One 256-thread workgroup per head: the split weights are formed once (one split per lane),
-// then the O rows are summed with the splits dealt over thread groups so the loads of
-// different splits are independent and in flight together.
-__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws,
-                                                         float* __restrict__ out, int hs,
-                                                         int nsplit_grid, int last_val,
-                                                         const int32_t* __restrict__ pos_dev) {
-  __shared__ float sf[kMaxSplits];
-  __shared__ float red[4];
-  __shared__ float part[256];
-  const int hq = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int last = pos_dev ? *pos_dev : last_val;
-  const int ntiles = (last >> 4) + 1;
-  const int tps = (ntiles + nsplit_grid - 1) / nsplit_grid;
-  const int nsplit = (ntiles + tps - 1) / tps;
-  if (nsplit == 1) return;  // the attention kernel wrote the final rows itself
-  const size_t stride = attn_ws_stride(hs);
-  const float* base = ws + (size_t)hq * nsplit_grid * stride;
-  // nsplit <= kMaxSplits = 64: wave 0 holds one split per lane
-  if (wave == 0) {
-    float m = -INFINITY, l = 0.f;
-    if (lane < nsplit) {
-      m = base[(size_t)lane * stride];
-      l = base[(size_t)lane * stride + 1];
+  // ---- the workgroup that arrives last for this kv head combines the splits ----
+  // Every storing wave drains its write-through stores before the workgroup takes a ticket.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = atomicInc(&tickets[kvh * (kTicketStride / sizeof(unsigned))], (unsigned)nsplit - 1u);  // wraps back to 0
+    sm_last = old == (unsigned)nsplit - 1u;
+  }
+  __syncthreads();
+  if (!sm_last) return;
+  // Acquire at device scope, then ordinary 128-bit loads of the other workgroups' partials.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // out[h][d] = sum_s O_s[d] e^{m_s-M} / sum_s l_s e^{m_s-M}.  One wave per head, no workgroup
+  // barriers: a row of HS floats is HS/4 lanes wide, the wave's RG row groups take the splits
+  // round-robin, and every load of a pass is in flight before the first is used.
+  constexpr int LPR = HS / 4;        // lanes per row
+  constexpr int RG = 64 / LPR;       // rows loaded per wave instruction
+  constexpr int PASS = 16;           // loads in flight per lane
+  const size_t stride = attn_ws_stride(HS);
+  const int c4 = (lane % LPR) * 4, rg = lane / LPR;
+  float* sf = sm_sf + wave * kMaxSplits;  // this wave's split weights
+  for (int head = wave; head < kv_mul; head += kAttnWaves) {
+    const float* base = ws + (size_t)(kvh * kv_mul + head) * gridDim.y * stride;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nsplit; s0 += PASS * RG) {
+      f32x4 ov[PASS];
+#pragma unroll
+      for (int k = 0; k < PASS; ++k) {
+        // rows past the last split re-read the last one; their weight below is zero
+        const unsigned sp = min(s0 + k * RG + rg, nsplit - 1);
+        ov[k] = *reinterpret_cast<const f32x4*>(base + sp * (unsigned)stride + c4);
+      }
+      if (s0 == 0) {
+        // split weights, one split per lane (two rounds cover kMaxSplits = 128)
+        float m[kMaxSplits / 64], l[kMaxSplits / 64];
+        float M = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < kMaxSplits / 64; ++c) {
+          const int sp = c * 64 + lane;
+          m[c] = -INFINITY;
+          l[c] = 0.f;
+          if (sp < nsplit) {
+            const float2 ml = *reinterpret_cast<const float2*>(base + (size_t)sp * stride + HS);
+            m[c] = ml.x;
+            l[c] = ml.y;
+          }
+          M = fmaxf(M, m[c]);
+        }
+        M = wave_max(M);
+        float f[kMaxSplits / 64], Lsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxSplits / 64; ++c) {
+          f[c] = c * 64 + lane < nsplit ? expf(m[c] - M) : 0.f;
+          Lsum += f[c] * l[c];
+        }
+        const float inv_l = 1.0f / wave_sum(Lsum);
+#pragma unroll
+        for (int c = 0; c < kMaxSplits / 64; ++c) sf[c * 64 + lane] = f[c] * inv_l;
+      }
+#pragma unroll
+      for (int k = 0; k < PASS; ++k) {
+        const int sp = s0 + k * RG + rg;
+        const float w = sp < nsplit ? sf[sp] : 0.f;
+        acc.x = fmaf(ov[k].x, w, acc.x);
+        acc.y = fmaf(ov[k].y, w, acc.y);
+        acc.z = fmaf(ov[k].z, w, acc.z);
+        acc.w = fmaf(ov[k].w, w, acc.w);
+      }
     }
-    const float M = wave_max(m);
-    const float f = lane < nsplit ? expf(m - M) : 0.f;
-    sf[lane] = f;
-    const float L = wave_sum(f * l);
-    if (lane == 0) red[0] = L;
-  }
-  __syncthreads();
-  const float inv_l = 1.0f / red[0];
-  // thread (group g, dim d): group g sums splits g, g+G, ...
-  const int G = 256 / hs > 0 ? 256 / hs : 1;
-  const int g = tid / hs, d = tid % hs;
-  float acc = 0.f;
-  if (g < G) {
-#pragma unroll 4
-    for (int s = g; s < nsplit; s += G) acc = fmaf(base[(size_t)s * stride + 2 + d], sf[s], acc);
-  }
-  part[tid] = acc;
-  __syncthreads();
-  if (tid < hs) {
-    float o = 0.f;
-    for (int k = 0; k < G; ++k) o += part[k * hs + tid];
-    out[(size_t)hq * hs + tid] = o * inv_l;
+    // fold the row groups
+#pragma unroll
+    for (int off = 32; off >= LPR; off >>= 1) {
+      acc.x += __shfl_xor(acc.x, off);
+      acc.y += __shfl_xor(acc.y, off);
+      acc.z += __shfl_xor(acc.z, off);
+      acc.w += __shfl_xor(acc.w, off);
+    }
+    if (rg == 0) *reinterpret_cast<f32x4*>(out + (size_t)(kvh * kv_mul + head) * HS + c4) = acc;
   }
 }
 
@@ -279,7 +366,8 @@ __global__ void attn_decode_generic_kernel(const float* __restrict__ q, const fl
 
 extern "C" size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size) {
   if (head_num <= 0 || head_size <= 0) return 0;
-  return (size_t)head_num * kx::kMaxSplits * kx::attn_ws_stride(head_size) * sizeof(float);
+  return kx::kTicketBytes +
+         (size_t)head_num * kx::kMaxSplits * kx::attn_ws_stride(head_size) * sizeof(float);
 }
 
 static int mha_decode_launch(const float* query, const float* key_cache, const float* value_cache,
@@ -303,11 +391,13 @@ static int mha_decode_launch(const float* query, const float* key_cache, const f
                      kv_dim % 4 == 0;
   if (!tiled) {
     if (pos_dev) return KX_EUNSUPPORTED;
-    if (!workspace || workspace_bytes < (size_t)head_num * seq_len * sizeof(float))
+    // the score rows sit behind the ticket words so the two paths can share one workspace
+    if (!workspace || workspace_bytes < kTicketBytes + (size_t)head_num * seq_len * sizeof(float))
       return KX_EWORKSPACE;
     hipLaunchKernelGGL(attn_decode_generic_kernel, dim3(head_num), dim3(256), 0,
-                       (hipStream_t)stream, query, kc, vc, out, reinterpret_cast<float*>(workspace),
-                       pos, kv_mul, kv_dim, head_size, seq_len, scale);
+                       (hipStream_t)stream, query, kc, vc, out,
+                       reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes), pos,
+                       kv_mul, kv_dim, head_size, seq_len, scale);
     KX_LAUNCH_CHECK();
     return KX_OK;
   }
@@ -315,43 +405,42 @@ static int mha_decode_launch(const float* query, const float* key_cache, const f
   // `pos` sizes the grid: the actual position when passed by value, the largest position the
   // launch may ever see when it is read from pos_dev.
   const int ntiles = (pos >> 4) + 1;
-  // one tile per wave is the finest useful cut; keep the grid near 2 workgroups per CU
+  // one tile per wave is the finest useful cut; keep the grid near 4 workgroups per CU
   int nsplit = (ntiles + kAttnWaves - 1) / kAttnWaves;
-  const int cap_grid = (512 + kvh - 1) / kvh;
+  const int cap_grid = (1024 + kvh - 1) / kvh;
   if (nsplit > cap_grid) nsplit = cap_grid;
   if (nsplit > kMaxSplits) nsplit = kMaxSplits;
+  if (kvh > kMaxTickets) return KX_EUNSUPPORTED;
   const size_t per_split = (size_t)head_num * attn_ws_stride(head_size) * sizeof(float);
   if (nsplit > 1) {
-    const size_t fit = workspace ? workspace_bytes / per_split : 0;
+    const size_t fit =
+        workspace && workspace_bytes > kTicketBytes ? (workspace_bytes - kTicketBytes) / per_split : 0;
     if (fit < (size_t)nsplit) nsplit = fit < 1 ? 1 : (int)fit;
   }
-  const int tps = (ntiles + nsplit - 1) / nsplit;
-  nsplit = (ntiles + tps - 1) / tps;  // no empty splits at `pos`
-  float* ws = reinterpret_cast<float*>(workspace);
+  const int tps = attn_tiles_per_split(ntiles, nsplit);
+  nsplit = (ntiles + tps - 1) / tps;  // no empty splits at `pos`; the kernel derives the same cut
+  unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
+  float* ws = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes) : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(kvh, nsplit), block(kAttnWaves * 64);
+  const bool prefetch = tps > kAttnWaves;
+#define KX_ATTN_LAUNCH(HS_)                                                                      \
+  do {                                                                                           \
+    if (prefetch)                                                                                \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, true>), grid, block, 0, s, query, kc, vc, out, \
+                         ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                      \
+    else                                                                                         \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, false>), grid, block, 0, s, query, kc, vc,     \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                 \
+  } while (0)
   switch (head_size) {
-    case 32:
-      hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, s, query, kc, vc, out, ws, pos,
-                         pos_dev, kv_mul, kv_dim, scale);
-      break;
-    case 64:
-      hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, s, query, kc, vc, out, ws, pos,
-                         pos_dev, kv_mul, kv_dim, scale);
-      break;
-    case 128:
-      hipLaunchKernelGGL(attn_decode_kernel<128>, grid, block, 0, s, query, kc, vc, out, ws, pos,
-                         pos_dev, kv_mul, kv_dim, scale);
-      break;
-    default:
-      return KX_EUNSUPPORTED;
+    case 32: KX_ATTN_LAUNCH(32); break;
+    case 64: KX_ATTN_LAUNCH(64); break;
+    case 128: KX_ATTN_LAUNCH(128); break;
+    default: return KX_EUNSUPPORTED;
   }
+#undef KX_ATTN_LAUNCH
   KX_LAUNCH_CHECK();
-  if (nsplit > 1) {
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(head_num), dim3(256), 0, s, ws, out, head_size,
-                       nsplit, pos, pos_dev);
-    KX_LAUNCH_CHECK();
-  }
   return KX_OK;
 }
 

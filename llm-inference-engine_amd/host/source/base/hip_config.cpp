@@ -24,13 +24,17 @@ int HipConfig::create_streams() {
 int HipConfig::reserve_attn_workspace(int head_num, int head_size, int seq_len) {
   size_t need = kx_attn_workspace_bytes(head_num, head_size);
   // the generic attention kernel wants a [head_num][seq_len] score scratch
-  const size_t score = (size_t)head_num * (size_t)seq_len * sizeof(float);
+  // behind the ticket words that head the workspace
+  const size_t score = 16384 + (size_t)head_num * (size_t)seq_len * sizeof(float);
   if (score > need) need = score;
   if (need <= attn_workspace_bytes) return 0;
   if (attn_workspace) kx_free(attn_workspace);
   attn_workspace = nullptr;
   attn_workspace_bytes = 0;
-  const int rc = kx_malloc(&attn_workspace, need);
+  int rc = kx_malloc(&attn_workspace, need);
+  // the split kernels count arrivals in the head of the workspace and expect it zeroed once
+  if (rc == 0) rc = kx_memset(attn_workspace, 0, need, nullptr);
+  if (rc == 0) rc = kx_device_sync();
   if (rc == 0) attn_workspace_bytes = need;
   return rc;
 }

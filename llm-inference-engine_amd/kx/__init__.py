@@ -196,6 +196,28 @@ class Stream:
             pass
 
 
+def time_graph(stream, record, replays=20):
+    """Captures the launches that `record()` issues on `stream` into a HIP graph, replays the graph
+    `replays` times and returns microseconds per replay (HIP events; no host launch cost inside)."""
+    g = C.c_void_p()
+    record()  # eager once: lazy per-kernel setup must not happen during capture
+    stream.sync()
+    check(lib().kx_graph_begin_capture(stream.ptr), "begin_capture")
+    record()
+    check(lib().kx_graph_end_capture(stream.ptr, C.byref(g)), "end_capture")
+    check(lib().kx_graph_launch(g, stream.ptr), "graph_launch")
+    stream.sync()
+    e0, e1 = Event(), Event()
+    e0.record(stream.ptr)
+    for _ in range(replays):
+        lib().kx_graph_launch(g, stream.ptr)
+    e1.record(stream.ptr)
+    e1.sync()
+    us = e0.elapsed_ms(e1) * 1e3 / replays
+    lib().kx_graph_destroy(g)
+    return us
+
+
 class Event:
     def __init__(self):
         p = C.c_void_p()
@@ -246,8 +268,8 @@ def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspa
     out = Buf.zeros(head_num * head_size)
     if workspace_bytes is None:
         workspace_bytes = max(lib().kx_attn_workspace_bytes(head_num, head_size),
-                              head_num * S * 4)
-    ws = Buf(workspace_bytes) if workspace_bytes else None
+                              16384 + head_num * S * 4)
+    ws = Buf.zeros(workspace_bytes, np.uint8) if workspace_bytes else None
     check(lib().kx_mha_decode_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos, head_num, kv_mul, head_size,
                                   kv_dim, S, layer_index, ws.ptr if ws else None, workspace_bytes,
                                   None), "kx_mha_decode_f32")
@@ -264,8 +286,8 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
     dq, dk, dv = Buf.from_numpy(q), Buf.from_numpy(kc.astype(np.float32)), \
         Buf.from_numpy(vc.astype(np.float32))
     out = Buf.zeros(q.size)
-    wsb = max(lib().kx_attn_workspace_bytes(head_num, head_size), head_num * S * 4)
-    ws = Buf(wsb)
+    wsb = max(lib().kx_attn_workspace_bytes(head_num, head_size), 16384 + head_num * S * 4)
+    ws = Buf.zeros(wsb, np.uint8)
     check(lib().kx_flash_attention_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, Tq, head_num, kv_head_num,
                                        head_size, S, pos, layer_idx, softmax_scale,
                                        1 if is_causal else 0, ws.ptr, wsb, None),

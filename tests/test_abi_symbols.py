@@ -40,7 +40,7 @@ def test_error_strings_without_gpu():
     assert L.kx_error_string(0) == b"ok"
     assert b"invalid" in L.kx_error_string(-1)
     assert b"unsupported" in L.kx_error_string(-2)
-    assert L.kx_attn_workspace_bytes(32, 128) == 32 * 64 * 130 * 4
+    assert L.kx_attn_workspace_bytes(32, 128) == 16384 + 32 * 128 * 132 * 4
 
 
 def test_missing_library_is_loud(monkeypatch):

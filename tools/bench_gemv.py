@@ -27,6 +27,9 @@ def algo_bytes(K, M):
 
 def main():
     which = sys.argv[1:] or ["8b", "1b"]
+    # bytes of distinct weights cycled through: > 256 MiB keeps every read cold (HBM); ~120e6 leaves
+    # the weights resident in the Infinity Cache but not in the 8 x 4 MiB L2s
+    footprint = float(os.environ.get("KX_BENCH_FOOTPRINT", "600e6"))
     L = kx.lib()
     st = kx.Stream()
     rng = np.random.default_rng(0)
@@ -34,25 +37,20 @@ def main():
     for name in which:
         for K, M in SHAPES[name]:
             per = K * M + 4 * K * M // GS
-            nbuf = max(2, min(64, int(600e6 // per) + 1))
+            nbuf = max(1, min(64, int(footprint // per) + 1))
             w = rng.integers(-127, 128, size=(K, M), dtype=np.int8)
             s = rng.uniform(1e-4, 3e-4, size=K * M // GS).astype(np.float32)
             ws = [kx.Buf.from_numpy(w) for _ in range(nbuf)]
             ss = [kx.Buf.from_numpy(s) for _ in range(nbuf)]
             x = kx.Buf.from_numpy(rng.standard_normal(M).astype(np.float32))
             y = kx.Buf.zeros(K)
-            iters = max(nbuf * 3, 60)
-            for i in range(nbuf):
-                kx.check(L.kx_gemv_w8_f32(x.ptr, ws[i].ptr, ss[i].ptr, GS, y.ptr, M, K, st.ptr))
-            st.sync()
-            e0, e1 = kx.Event(), kx.Event()
-            e0.record(st.ptr)
-            for i in range(iters):
-                j = i % nbuf
-                L.kx_gemv_w8_f32(x.ptr, ws[j].ptr, ss[j].ptr, GS, y.ptr, M, K, st.ptr)
-            e1.record(st.ptr)
-            e1.sync()
-            us = e0.elapsed_ms(e1) * 1e3 / iters
+            reps = max(1, 64 // nbuf)
+
+            def record():
+                for _ in range(reps):
+                    for j in range(nbuf):
+                        kx.check(L.kx_gemv_w8_f32(x.ptr, ws[j].ptr, ss[j].ptr, GS, y.ptr, M, K, st.ptr))
+            us = kx.time_graph(st, record) / (reps * nbuf)
             gbs = algo_bytes(K, M) / us / 1e3
             print(f"{name} K={K:6d} M={M:6d} nbuf={nbuf:3d} {us:9.2f} us  {gbs:8.1f} GB/s  "
                   f"{gbs / 8000 * 100:5.1f}% of 8TB/s", flush=True)
