@@ -10,10 +10,12 @@
 // register, x is staged once per workgroup in LDS in a layout that makes the four 16-byte
 // reads per weight load conflict-free, and the row sum is finished with DPP + swizzle.
 // The first batch of weight loads is issued before x is staged so the HBM round trip and the
-// L2 round trip for x overlap.
+// L2 round trip for x overlap; bias, residual and rotation operands are requested before the
+// chunk loop so no dependent load is left for the tail.
 //
 // Optional fusions used by the token loop (each replaces a separate launch of the reference):
-//   - RMSNorm of x while staging it           (rmsnorm_kernel.cu:62-108, llama3.cpp:637-646)
+//   - RMSNorm of x while staging it           (rmsnorm_kernel.cu:62-108, llama3.cpp:637-646):
+//     g*x is staged and the scalar rsqrt(mean(x^2)+eps) multiplies the finished row sums
 //   - bias / residual add in the epilogue      (matmul.cpp:76-79, llama3.cpp:751-752,787)
 //   - [Wq;Wk;Wv] in one launch with RoPE applied to the finished q/k pairs and k, v written
 //     straight into their KV-cache row        (llama3.cpp:648-677, rope_kernel.cu)
@@ -82,12 +84,17 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
                                            int col_lane, i32x4 (&wv)[R][U], float (&sc)[R][U],
                                            i32x4 (&wv2)[R2][U2], float (&sc2)[R2][U2]) {
   constexpr bool GU = MODE == GEMV_GATE_UP;
+  int rows[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
+  for (int r = 0; r < R; ++r) rows[r] = map_row<MODE>(a, min(r0 + r, row_end - 1));
+  // issue order = consumption order (chunk-major), so the first products can start while the
+  // later loads are still in flight
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int col = (c0 + u) * 1024 + col_lane;
+  for (int u = 0; u < U; ++u) {
+    const int col = (c0 + u) * 1024 + col_lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rows[r];
       if (col < a.M) {
         const size_t off = (size_t)row * (size_t)a.M + (size_t)col;
         wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
@@ -109,6 +116,45 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
       }
     }
   }
+}
+
+// Stages x in LDS: slot (c*4+p)*64+l <- x[c*1024 + l*16 + p*4 .. +4), zero past M.  With a norm
+// weight g the staged vector is g*x and the function returns rsqrt(mean(x^2)+eps), which the
+// caller applies to the finished row sums: norm_w * (rs * x) of cpu/rmsnorm_kernel.cpp:30-32 with
+// the scalar factored out of the dot product.  Ends with one workgroup barrier.
+__device__ __forceinline__ float stage_x(const GemvW8Args& a, f32x4* xs, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
+  const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w);
+  const int n4 = a.chunks * 256;
+  const int m4 = a.M >> 2;
+  float ss = 0.f;
+  for (int i = tid; i < n4; i += blockDim.x) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < m4) {
+      v = xg[i];
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      if (ng) {
+        const f32x4 g = ng[i];
+        v = f32x4{g.x * v.x, g.y * v.y, g.z * v.z, g.w * v.w};
+      }
+    }
+    const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
+    xs[((c * 4 + p) << 6) + l] = v;
+  }
+  float rs = 1.0f;
+  if (ng) {
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+  }
+  __syncthreads();
+  if (ng) {
+    float tot = 0.f;
+    for (int w = 0; w < nwaves; ++w) tot += red[w];
+    rs = 1.0f / sqrtf(tot / (float)a.M + a.norm_eps);
+  }
+  return rs;
 }
 
 // R rows per wave at a time (R even for GEMV_QKV_ROPE), U chunk loads per row in flight.
@@ -140,38 +186,15 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
   const int r_first = row_begin + wave * R;
   const bool active = r_first < row_end;
 
-  // ---- stage x: slot (c*4+p)*64+l  <-  x[c*1024 + l*16 + p*4 .. +4) ; zero past M ----
-  {
-    const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
-    const int n4 = a.chunks * 256;
-    const int m4 = M >> 2;
-    float ss = 0.f;
-    for (int i = tid; i < n4; i += blockDim.x) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < m4) v = xg[i];
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
-      xs[((c * 4 + p) << 6) + l] = v;
-    }
-    if (a.norm_w) {
-      // rmsnorm (cpu/rmsnorm_kernel.cpp:30-32): x <- norm_w * (rsqrt(mean(x^2)+eps) * x)
-      ss = wave_sum(ss);
-      if (lane == 0) red[wave] = ss;
-      __syncthreads();
-      float tot = 0.f;
-      for (int w = 0; w < nwaves; ++w) tot += red[w];
-      const float rs = 1.0f / sqrtf(tot / (float)M + a.norm_eps);
-      const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w);
-      for (int i = tid; i < m4; i += blockDim.x) {
-        const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
-        const int slot = ((c * 4 + p) << 6) + l;
-        const f32x4 v = xs[slot], g = ng[i];
-        xs[slot] = f32x4{g.x * (rs * v.x), g.y * (rs * v.y), g.z * (rs * v.z), g.w * (rs * v.w)};
-      }
-    }
+  // A wave without rows only helps staging x.  The others request their first batch of weights
+  // BEFORE staging (inside the loop below, first trip), so the HBM round trip of the weights
+  // overlaps the L2 round trip and the optional normalisation of x.
+  if (!active) {
+    stage_x(a, xs, red);
+    return;
   }
-  __syncthreads();
-  if (!active) return;
+  bool staged = false;
+  float rs = 1.0f;
 
   int pos = 0;
   if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
@@ -183,9 +206,33 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
     for (int r = 0; r < R; ++r) total[r] = 0.f;
 #pragma unroll
     for (int r = 0; r < R2; ++r) total2[r] = 0.f;
+    // epilogue operands are requested now, not after the reduction: bias + residual per row,
+    // and the rotation's sin/cos per pair
+    float addend[R];
+    float rope_s[R / 2 > 0 ? R / 2 : 1], rope_c[R / 2 > 0 ? R / 2 : 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int v = min(r0 + r, row_end - 1);
+      const int row = map_row<MODE>(a, v);
+      addend[r] = 0.f;
+      if (a.bias) addend[r] += a.bias[row];
+      if constexpr (MODE != GEMV_QKV_ROPE) {
+        if (a.residual) addend[r] += a.residual[row];
+      } else if ((r & 1) == 0) {
+        // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
+        const int in_head = row % a.head_size;
+        const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
+        rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
+        rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];
+      }
+    }
 
     for (int c0 = 0; c0 < a.chunks; c0 += U) {
       load_batch<R, U, R2, U2, MODE>(a, r0, c0, row_end, col_lane, wv, sc, wv2, sc2);
+      if (!staged) {
+        rs = stage_x(a, xs, red);
+        staged = true;
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (c0 + u < a.chunks) {
@@ -205,9 +252,9 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      total[r] = wave_sum(total[r]);
+      total[r] = wave_sum(total[r]) * rs;
       if constexpr (GU) {
-        const float up = wave_sum(total2[r]);
+        const float up = wave_sum(total2[r]) * rs;
         // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
         total[r] = total[r] * (1.0f / (1.0f + expf(-total[r]))) * up;
       }
@@ -219,18 +266,9 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
           const int v = r0 + r;
           if (v < row_end) {  // row counts are even, so v+1 is valid too
             const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
-            float o0 = total[r], o1 = total[r + 1];
-            if (a.bias) {
-              o0 += a.bias[row0];
-              o1 += a.bias[row1];
-            }
+            float o0 = total[r] + addend[r], o1 = total[r + 1] + addend[r + 1];
             if (v < a.k1) {
-              // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
-              const int hs = a.head_size;
-              const int in_head = row0 % hs;
-              const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
-              const float fci = a.sin_cache[(size_t)pos * hs + tab];
-              const float fcr = a.cos_cache[(size_t)pos * hs + tab];
+              const float fci = rope_s[r / 2], fcr = rope_c[r / 2];
               const float t0 = o0 * fcr - o1 * fci;
               const float t1 = o0 * fci + o1 * fcr;
               o0 = t0;
@@ -249,9 +287,7 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
         for (int r = 0; r < R; ++r) {
           const int row = r0 + r;
           if (row < row_end) {
-            float v = total[r];
-            if (a.bias) v += a.bias[row];
-            if (a.residual) v += a.residual[row];
+            const float v = total[r] + addend[r];
             float* dst;
             int rr;
             route(a, row, 0, dst, rr);

@@ -56,17 +56,13 @@ def main():
                 d.sin_cache, d.cos_cache, d.pos_dev = sin.ptr, cos.ptr, pos.ptr
                 d.rope_variant, d.head_size, d.kv_pos_stride = 1, hs, kvd
             descs.append(d)
-        for d in descs:
-            kx.check(L.kx_gemv_w8_fused_f32(C.byref(d), st.ptr), name)
-        st.sync()
-        iters = max(3 * nbuf, 60)
-        e0, e1 = kx.Event(), kx.Event()
-        e0.record(st.ptr)
-        for i in range(iters):
-            L.kx_gemv_w8_fused_f32(C.byref(descs[i % nbuf]), st.ptr)
-        e1.record(st.ptr)
-        e1.sync()
-        us = e0.elapsed_ms(e1) * 1e3 / iters
+        reps = max(1, 48 // nbuf)
+
+        def record():
+            for _ in range(reps):
+                for d in descs:
+                    kx.check(L.kx_gemv_w8_fused_f32(C.byref(d), st.ptr), name)
+        us = kx.time_graph(st, record) / (reps * nbuf)
         b = K * M + 4 * K * M // GS + 4 * (M + K)
         print(f"{name:16s} K={K:6d} M={M:6d} {us:8.2f} us {b / us / 1e3:8.1f} GB/s", flush=True)
 
