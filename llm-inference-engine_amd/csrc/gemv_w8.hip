@@ -157,145 +157,166 @@ __device__ __forceinline__ float stage_x(const GemvW8Args& a, f32x4* xs, float* 
   return rs;
 }
 
+// One batch of weights in registers: R rows x U chunks (and the paired "up" rows for gate/up).
+template <int R, int U, bool GU>
+struct GemvBatch {
+  i32x4 wv[R][U];
+  float sc[R][U];
+  i32x4 wv2[GU ? R : 1][GU ? U : 1];
+  float sc2[GU ? R : 1][GU ? U : 1];
+};
+
+// Row totals and the epilogue operands of the R rows a wave is working on.
+template <int R, bool GU>
+struct GemvRows {
+  float total[R];
+  float total2[GU ? R : 1];
+  float addend[R];                     // bias + residual
+  float rope_s[R / 2 > 0 ? R / 2 : 1];  // sin / cos of each rotation pair
+  float rope_c[R / 2 > 0 ? R / 2 : 1];
+};
+
+// Clears the totals and requests the epilogue operands now, not after the reduction, so no
+// dependent load is left for the tail.
+template <int R, int MODE>
+__device__ __forceinline__ void begin_rows(const GemvW8Args& a, int r0, int row_end, int pos,
+                                           GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    S.total[r] = 0.f;
+    if constexpr (MODE == GEMV_GATE_UP) S.total2[r] = 0.f;
+    const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
+    S.addend[r] = 0.f;
+    if (a.bias) S.addend[r] += a.bias[row];
+    if constexpr (MODE != GEMV_QKV_ROPE) {
+      if (a.residual) S.addend[r] += a.residual[row];
+    } else if ((r & 1) == 0) {
+      // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
+      const int in_head = row % a.head_size;
+      const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
+      S.rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
+      S.rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];
+    }
+  }
+}
+
+// Products of one batch against the staged x.
+template <int R, int U, int MODE>
+__device__ __forceinline__ void consume(const GemvW8Args& a, const f32x4* xs, int lane, int c0,
+                                        const GemvBatch<R, U, MODE == GEMV_GATE_UP>& B,
+                                        GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (c0 + u < a.chunks) {
+      const int base = ((c0 + u) * 4) << 6;
+      const f32x4 x0 = xs[base + lane];
+      const f32x4 x1 = xs[base + 64 + lane];
+      const f32x4 x2 = xs[base + 128 + lane];
+      const f32x4 x3 = xs[base + 192 + lane];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        S.total[r] = fmaf(dot16(B.wv[r][u], x0, x1, x2, x3), B.sc[r][u], S.total[r]);
+        if constexpr (MODE == GEMV_GATE_UP)
+          S.total2[r] = fmaf(dot16(B.wv2[r][u], x0, x1, x2, x3), B.sc2[r][u], S.total2[r]);
+      }
+    }
+  }
+}
+
+// Wave reduction and epilogue of R finished rows.
+template <int R, int MODE>
+__device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row_end, int pos,
+                                            float rs, int lane,
+                                            GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    S.total[r] = wave_sum(S.total[r]) * rs;
+    if constexpr (MODE == GEMV_GATE_UP) {
+      const float up = wave_sum(S.total2[r]) * rs;
+      // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
+      S.total[r] = S.total[r] * (1.0f / (1.0f + expf(-S.total[r]))) * up;
+    }
+  }
+  if (lane != 0) return;
+  if constexpr (MODE == GEMV_QKV_ROPE) {
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      const int v = r0 + r;
+      if (v < row_end) {  // row counts are even, so v+1 is valid too
+        const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
+        float o0 = S.total[r] + S.addend[r], o1 = S.total[r + 1] + S.addend[r + 1];
+        if (v < a.k1) {
+          const float fci = S.rope_s[r / 2], fcr = S.rope_c[r / 2];
+          const float t0 = o0 * fcr - o1 * fci;
+          const float t1 = o0 * fci + o1 * fcr;
+          o0 = t0;
+          o1 = t1;
+        }
+        float* dst;
+        int rr;
+        route(a, row0, pos, dst, rr);
+        dst[rr] = o0;
+        route(a, row1, pos, dst, rr);
+        dst[rr] = o1;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r0 + r;
+      if (row < row_end) {
+        float* dst;
+        int rr;
+        route(a, row, 0, dst, rr);
+        dst[rr] = S.total[r] + S.addend[r];
+      }
+    }
+  }
+}
+
 // R rows per wave at a time (R even for GEMV_QKV_ROPE), U chunk loads per row in flight.
+// For shapes where a wave gets a single batch (or a few).
 template <int R, int U, int MODE>
 __global__ void gemv_w8_kernel(const GemvW8Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* xs = reinterpret_cast<f32x4*>(smem);
   __shared__ float red[16];
   constexpr bool GU = MODE == GEMV_GATE_UP;
-  constexpr int R2 = GU ? R : 1;
-  constexpr int U2 = GU ? U : 1;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int nwaves = blockDim.x >> 6;
-  const int M = a.M;
   const int out_rows = GU ? a.swiglu_half : a.K;
   const int row_begin = blockIdx.x * a.rows_per_block;
   const int row_end = min(row_begin + a.rows_per_block, out_rows);
   const int col_lane = lane * 16;
-
-  i32x4 wv[R][U];
-  float sc[R][U];
-  i32x4 wv2[R2][U2];
-  float sc2[R2][U2];
-
-
   const int r_first = row_begin + wave * R;
-  const bool active = r_first < row_end;
 
   // A wave without rows only helps staging x.  The others request their first batch of weights
   // BEFORE staging (inside the loop below, first trip), so the HBM round trip of the weights
   // overlaps the L2 round trip and the optional normalisation of x.
-  if (!active) {
+  if (r_first >= row_end) {
     stage_x(a, xs, red);
     return;
   }
   bool staged = false;
   float rs = 1.0f;
-
   int pos = 0;
   if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
 
+  GemvBatch<R, U, GU> B;
+  GemvRows<R, GU> S;
   for (int r0 = r_first; r0 < row_end; r0 += nwaves * R) {
-    float total[R];
-    float total2[R2];
-#pragma unroll
-    for (int r = 0; r < R; ++r) total[r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < R2; ++r) total2[r] = 0.f;
-    // epilogue operands are requested now, not after the reduction: bias + residual per row,
-    // and the rotation's sin/cos per pair
-    float addend[R];
-    float rope_s[R / 2 > 0 ? R / 2 : 1], rope_c[R / 2 > 0 ? R / 2 : 1];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int v = min(r0 + r, row_end - 1);
-      const int row = map_row<MODE>(a, v);
-      addend[r] = 0.f;
-      if (a.bias) addend[r] += a.bias[row];
-      if constexpr (MODE != GEMV_QKV_ROPE) {
-        if (a.residual) addend[r] += a.residual[row];
-      } else if ((r & 1) == 0) {
-        // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
-        const int in_head = row % a.head_size;
-        const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
-        rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
-        rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];
-      }
-    }
-
+    begin_rows<R, MODE>(a, r0, row_end, pos, S);
     for (int c0 = 0; c0 < a.chunks; c0 += U) {
-      load_batch<R, U, R2, U2, MODE>(a, r0, c0, row_end, col_lane, wv, sc, wv2, sc2);
+      load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2,
+                                                    B.sc2);
       if (!staged) {
         rs = stage_x(a, xs, red);
         staged = true;
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (c0 + u < a.chunks) {
-          const int base = ((c0 + u) * 4) << 6;
-          const f32x4 x0 = xs[base + lane];
-          const f32x4 x1 = xs[base + 64 + lane];
-          const f32x4 x2 = xs[base + 128 + lane];
-          const f32x4 x3 = xs[base + 192 + lane];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            total[r] = fmaf(dot16(wv[r][u], x0, x1, x2, x3), sc[r][u], total[r]);
-            if constexpr (GU)
-              total2[r] = fmaf(dot16(wv2[r][u], x0, x1, x2, x3), sc2[r][u], total2[r]);
-          }
-        }
-      }
+      consume<R, U, MODE>(a, xs, lane, c0, B, S);
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      total[r] = wave_sum(total[r]) * rs;
-      if constexpr (GU) {
-        const float up = wave_sum(total2[r]) * rs;
-        // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
-        total[r] = total[r] * (1.0f / (1.0f + expf(-total[r]))) * up;
-      }
-    }
-    if (lane == 0) {
-      if constexpr (MODE == GEMV_QKV_ROPE) {
-#pragma unroll
-        for (int r = 0; r < R; r += 2) {
-          const int v = r0 + r;
-          if (v < row_end) {  // row counts are even, so v+1 is valid too
-            const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
-            float o0 = total[r] + addend[r], o1 = total[r + 1] + addend[r + 1];
-            if (v < a.k1) {
-              const float fci = rope_s[r / 2], fcr = rope_c[r / 2];
-              const float t0 = o0 * fcr - o1 * fci;
-              const float t1 = o0 * fci + o1 * fcr;
-              o0 = t0;
-              o1 = t1;
-            }
-            float* dst;
-            int rr;
-            route(a, row0, pos, dst, rr);
-            dst[rr] = o0;
-            route(a, row1, pos, dst, rr);
-            dst[rr] = o1;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int row = r0 + r;
-          if (row < row_end) {
-            const float v = total[r] + addend[r];
-            float* dst;
-            int rr;
-            route(a, row, 0, dst, rr);
-            dst[rr] = v;
-          }
-        }
-      }
-    }
+    finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
   }
 }
 
@@ -378,16 +399,17 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
   int threads = 256;
   if (lds > 32 * 1024) threads = 512;
   if (lds > 80 * 1024) threads = 1024;
-  const int waves = threads / 64;
   const int out_rows = mode == GEMV_GATE_UP ? a.swiglu_half : a.K;
   // rows a wave keeps in flight together; the gate/up form already doubles the loads
   const int R = mode == GEMV_GATE_UP ? 1 : (a.chunks <= 2 ? 4 : 2);
-  const int per_iter = waves * R;
+  const int per_iter = (threads / 64) * R;
   // aim for ~4 workgroups per CU on big matrices, one pass on small ones
   const int target_blocks = 256 * 4;
   int rpb = (out_rows + target_blocks - 1) / target_blocks;
   rpb = ((rpb + per_iter - 1) / per_iter) * per_iter;
   a.rows_per_block = rpb;
+  // (R, U) per mode from a sweep on MI355X: more loads per wave than these lowers occupancy and
+  // loses; two register sets per wave (software pipelining) lost 30 % against plain occupancy
   switch (mode) {
     case GEMV_GATE_UP:
       return a.chunks <= 2 ? launch<1, 2, GEMV_GATE_UP>(a, threads, s)
@@ -395,7 +417,7 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
     case GEMV_QKV_ROPE:
       if (a.K % 2 || a.k0 % 2 || a.k1 % 2 || a.head_size % 2) return KX_EINVAL;
       return a.chunks <= 2 ? launch<4, 2, GEMV_QKV_ROPE>(a, threads, s)
-                           : launch<2, 4, GEMV_QKV_ROPE>(a, threads, s);
+                           : launch<2, 2, GEMV_QKV_ROPE>(a, threads, s);
     default:
       return a.chunks <= 2 ? launch<4, 2, GEMV_PLAIN>(a, threads, s)
                            : launch<2, 4, GEMV_PLAIN>(a, threads, s);
