@@ -26,6 +26,66 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix peak
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_gemv_traffic.json")
+
+
+def measured_traffic():
+    """HBM bytes per GEMV launch from the committed rocprofv3 --pmc passes over this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied by
+    tools/collect_traffic.py).  Counters cannot be read from inside the process, so the figure is
+    the stored one; None if the file is absent."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def prefill_kernels(kx, shape, tp, T=4096):
+    """Times the two MFMA prefill kernels standalone on this rank's geometry: causal flash
+    attention over T rows (FLOPs 4*hs*T*(T+1)/2 per head) and the W8A16 GEMM of the widest layer
+    matrix (FLOPs 2*T*K*M)."""
+    L = kx.lib()
+    st = kx.Stream()
+    H, KVH = shape["head_num"] // tp, shape["kv_head_num"] // tp
+    hs = shape["dim"] // shape["head_num"]
+    kvd = KVH * hs
+    q = kx.Buf(T * H * hs * 4)
+    kc, vc = kx.Buf(T * kvd * 4), kx.Buf(T * kvd * 4)
+    out = kx.Buf(T * H * hs * 4)
+    for buf, n, seed in ((q, T * H * hs, 3), (kc, T * kvd, 4), (vc, T * kvd, 5)):
+        kx.check(L.kx_fill_hash_f32(buf.ptr, 1, n, n, 0, 0, seed, -1.0, 1.0, st.ptr), "fill")
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    scale = float(1.0 / np.sqrt(hs))
+
+    def fa():
+        kx.check(L.kx_flash_attention_f32(q.ptr, kc.ptr, vc.ptr, out.ptr, T, H, KVH, hs, T, T - 1, 0,
+                                          scale, 1, ws.ptr, wsb, st.ptr), "flash_attention")
+    fa_us = kx.time_graph(st, fa, replays=5)
+    fa_flops = 4.0 * hs * T * (T + 1) / 2 * H
+    K, M = 2 * shape["hidden_dim"] // tp, shape["dim"]
+    w = kx.Buf(K * M)
+    sc = kx.Buf(K * M // 64 * 4)
+    X = kx.Buf(T * M * 4)
+    Y = kx.Buf(T * K * 4)
+    kx.check(L.kx_fill_hash_i8(w.ptr, K, M, M, 0, 0, 7, st.ptr), "fill")
+    kx.check(L.kx_fill_hash_f32(sc.ptr, K, M // 64, M // 64, 0, 0, 8, 1e-4, 3e-4, st.ptr), "fill")
+    kx.check(L.kx_fill_hash_f32(X.ptr, T, M, M, 0, 0, 9, -1.0, 1.0, st.ptr), "fill")
+
+    def gemm():
+        kx.check(L.kx_gemm_w8_f32(X.ptr, w.ptr, sc.ptr, 64, Y.ptr, T, M, K, st.ptr), "gemm_w8")
+    gemm_us = kx.time_graph(st, gemm, replays=5)
+    gemm_flops = 2.0 * T * K * M
+    return {
+        "flash_attention": {"rows": T, "heads": H, "head_size": hs, "us": fa_us,
+                            "tflops": fa_flops / fa_us / 1e6,
+                            "mfma_util": fa_flops / fa_us / 1e6 / MFMA_F16_PEAK_TFLOPS},
+        "gemm_w8": {"T": T, "K": K, "M": M, "us": gemm_us, "tflops": gemm_flops / gemm_us / 1e6,
+                    "mfma_util": gemm_flops / gemm_us / 1e6 / MFMA_F16_PEAK_TFLOPS},
+        "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
+    }
 
 
 def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
@@ -79,6 +139,7 @@ def main():
                     help="prompt length filled into the KV cache before the timed decode")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill-kernels", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=4)
     args = ap.parse_args()
 
@@ -178,7 +239,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic() if args.model == "llama-3-8b" and world == 1 else None,
+                "traffic_source": "profiles/r01_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes, bytes per launch)",
                 "kernel": "gemv_w8_kernel (all W8 GEMV launches of a decode step, per rank)",
                 "launches_timed": n_launch,
                 "algorithmic_bytes_per_launch": gemv_bytes / max(n_launch, 1),
@@ -187,6 +250,8 @@ def main():
             "decode_hbm_gbps_end_to_end": (bpt + kv_bytes) * tok_s / 1e9 / world,
             "prefill_tok_per_s": args.context / prefill_s if args.context else None,
         }
+        if not args.no_prefill_kernels:
+            line["prefill_kernels"] = prefill_kernels(kx, shape, world)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, bpt)
         print(json.dumps(line), flush=True)
