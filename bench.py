@@ -6,6 +6,8 @@ MI355X, tensor-parallel over N GPUs of one node.
 
 A "step" is one decode token: one pass of the hot path (every W8 GEMV of the model + the
 flash-decode attention over the KV cache) with token id and position resident on the device.
+The default run is the Llama-3-8B configuration: a 4096-token prompt through the flash-attention
+prefill, then 512 timed decode tokens.
 Weights are seeded synthetic int8 + fp32 group scales generated in HBM, the prompt is synthetic
 token ids.  Rank 0 prints ONE JSON line.
 
@@ -132,7 +134,7 @@ def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--context", type=int, default=4096,
@@ -201,7 +203,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: the W8 GEMV.  Per-launch HIP events on the compute stream, eager launches.
+    # dominant kernel: the W8 GEMV.  The GEMV launches of one step, on the model's own buffers and
+    # in model order, replayed alone from a graph between two HIP events on the compute stream.
     n_launch, gemv_bytes, gemv_ms = model.profile_gemv(args.profile_steps)
     fence()
     tok, pos = model.state()

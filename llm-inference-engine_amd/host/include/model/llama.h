@@ -103,8 +103,8 @@ class LlamaModel {
   base::Status read_kv(int32_t layer, int32_t rows, float* k_host, float* v_host) const;
   base::Status sync() const;
 
-  // Per-launch timing of the W8 GEMV entries inside one fused step (HIP events on the compute
-  // stream): returns launches, summed algorithmic bytes and summed milliseconds.
+  // Timing of the W8 GEMV launches of a decode step (replayed alone from a graph, `steps` times,
+  // between two HIP events on the compute stream): launches, algorithmic bytes, milliseconds.
   base::Status profile_gemv(int32_t steps, int64_t* launches, double* bytes, double* ms);
 
   const TransformerConfig& config() const { return cfg_; }
@@ -167,11 +167,10 @@ class LlamaModel {
   struct RefLayers;
   std::unique_ptr<RefLayers> ref_;
 
-  // profiling
+  // profiling (profile_gemv)
   bool prof_on_ = false;
-  std::vector<std::pair<void*, void*>> prof_events_;
-  std::vector<double> prof_bytes_;
-  size_t prof_cursor_ = 0;
+  int64_t prof_launches_ = 0;
+  double prof_bytes_sum_ = 0;
 };
 
 }  // namespace model
