@@ -76,8 +76,12 @@ def prefill_kernels(kx, shape, tp, T=4096):
     kx.check(L.kx_fill_hash_f32(sc.ptr, K, M // 64, M // 64, 0, 0, 8, 1e-4, 3e-4, st.ptr), "fill")
     kx.check(L.kx_fill_hash_f32(X.ptr, T, M, M, 0, 0, 9, -1.0, 1.0, st.ptr), "fill")
 
-    def gemm():
-        kx.check(L.kx_gemm_w8_f32(X.ptr, w.ptr, sc.ptr, 64, Y.ptr, T, M, K, st.ptr), "gemm_w8")
+    gwsb = L.kx_gemm_w8_workspace_bytes(T, M, K)
+    gws = kx.Buf(gwsb)
+
+    def gemm():  # conversion passes included
+        kx.check(L.kx_gemm_w8_f32_ws(X.ptr, M, w.ptr, sc.ptr, 64, Y.ptr, K, None, 0, None, 0, K, K,
+                                     None, 0, T, M, K, gws.ptr, gwsb, st.ptr), "gemm_w8")
     gemm_us = kx.time_graph(st, gemm, replays=5)
     gemm_flops = 2.0 * T * K * M
     return {

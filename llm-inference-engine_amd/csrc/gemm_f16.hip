@@ -1,0 +1,249 @@
+// Two-pass W8A16 GEMM for long prompts, gfx950:  Y[T][K] = X[T][M] . W[K][M]^T  with
+//   Y[t][p] = sum_i X[t][i] * scales[(p*M+i)/gs] * (float)w[p*M+i]
+// (the per-row formula of matmul_kernel_cu_fp32int8, kuiper/source/op/kernels/cuda/
+// matmul_kernel.cu:56-87, applied to T rows; the reference itself has no batched matmul).
+//
+// The single-pass kernel in gemm_w8.hip converts int8 -> fp16 and applies the group scales inside
+// its main loop, once per 128-row tile of X: with thousands of rows that vector work, not the
+// matrix pipe, bounds it.  Here the conversions are done ONCE per call into a caller-provided
+// workspace, and the main loop is a plain fp16 MFMA GEMM:
+//   pass 1a  X fp32 -> fp16
+//   pass 1b  W int8 * group scale / f[p] -> fp16, where f[p] is a power of two per output row p
+//            that brings the row's largest scaled weight to <= 1 (keeps small scales out of the
+//            fp16 subnormal range); f is kept in fp32 and multiplied back in the epilogue
+//   pass 2   Y = (X16 . W16^T) * f, fp32 accumulation on v_mfma_f32_32x32x16_f16, tiles staged by
+//            LDS-DMA, with the routing / residual epilogue of the single-pass kernel
+// Deviation from the fp32 formula: one fp16 rounding of X and one of (scale * w), each 2^-11
+// relative, independent per element.
+#include <math.h>
+
+#include "kx_common.hpp"
+
+namespace kx {
+
+constexpr int GF_BM = 128, GF_BN = 128, GF_BK = 64;
+
+struct GemmF16Args {
+  const _Float16* X;   // [T][M]
+  const _Float16* W;   // [K][M]
+  const float* colf;   // [K] power-of-two row factors
+  const float* residual;
+  float* y0; float* y1; float* y2;
+  int64_t ld0, ld1, ld2, ldr;
+  int32_t k0, k1;
+  int32_t T, M, K;
+};
+
+// X fp32 [T][ldx] -> fp16 [T][M]
+__global__ void f32_to_f16_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                       _Float16* __restrict__ y, int M, int64_t n4) {
+  const int m4 = M / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / m4;
+    const int c = (int)(i - t * m4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * ldx + c);
+    f16x4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    *reinterpret_cast<f16x4*>(y + t * M + c) = h;
+  }
+}
+
+// One wave per weight row: W16[p][i] = fp16(w[p][i] * s[p][i/gs] / f[p]).
+__global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __restrict__ w,
+                                                              const float* __restrict__ scales,
+                                                              _Float16* __restrict__ w16,
+                                                              float* __restrict__ colf, int M, int K,
+                                                              int gs_shift) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= K) return;
+  const int groups = M >> gs_shift;
+  const float* sp = scales + (size_t)p * groups;
+  float mx = 0.f;
+  for (int g = lane; g < groups; g += 64) mx = fmaxf(mx, fabsf(sp[g]));
+  mx = wave_max(mx) * 127.0f;
+  // smallest power of two >= the row's largest scaled weight (1 for an all-zero row)
+  const float f = mx > 0.f ? exp2f(ceilf(log2f(mx))) : 1.0f;
+  const float inv = 1.0f / f;
+  if (lane == 0) colf[p] = f;
+  const int8_t* wp = w + (size_t)p * M;
+  _Float16* op = w16 + (size_t)p * M;
+  for (int c = lane * 16; c < M; c += 1024) {
+    const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + c));
+    const float s = sp[c >> gs_shift] * inv;
+    const int32_t words[4] = {v.x, v.y, v.z, v.w};
+    f16x8 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = (_Float16)((float)(int8_t)(words[0] >> (8 * e)) * s);
+      lo[4 + e] = (_Float16)((float)(int8_t)(words[1] >> (8 * e)) * s);
+      hi[e] = (_Float16)((float)(int8_t)(words[2] >> (8 * e)) * s);
+      hi[4 + e] = (_Float16)((float)(int8_t)(words[3] >> (8 * e)) * s);
+    }
+    *reinterpret_cast<f16x8*>(op + c) = lo;
+    *reinterpret_cast<f16x8*>(op + c + 8) = hi;
+  }
+}
+
+// 128 x 128 output tile per 256-thread workgroup (4 waves, 2 x 2, 64 x 64 each), K-step 64,
+// operands brought in by the LDS-DMA path (global_load_lds, 16 bytes per lane): no
+// staging registers, no ds_write pass.  One 32 KiB buffer, two barriers per K-step; several
+// workgroups per CU overlap each other's load and MFMA phases.  A wave instruction fills 1 KiB
+// of LDS linearly (8 rows of 128 bytes), so rows cannot be padded: the 16-byte chunk c of row r
+// is kept at chunk position c ^ ((r >> 1) & 7) instead (applied to the SOURCE address when
+// filling and to the LDS address when reading), which spreads any 16 consecutive rows of one
+// fragment column over all 64 banks.
+__global__ __launch_bounds__(256, 4) void gemm_f16_kernel(const GemmF16Args a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using lds_ptr_t = __attribute__((address_space(3))) void*;
+  constexpr int TILE_BYTES = GF_BM * GF_BK * 2;  // 16 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_m = (a.T + GF_BM - 1) / GF_BM;
+  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int t0 = tile_m * GF_BM, n0 = tile_n * GF_BN;
+  const int ksteps = a.M / GF_BK;
+
+  // fill roles: instruction i of wave w covers tile rows 8*(4i + w) .. +8; lane -> row l>>3,
+  // chunk position l&7, source chunk (l&7) ^ swizzle(row)
+  const _Float16* asrc[4];
+  const _Float16* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * i + wave) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    // rows past the end re-read the last valid row; their outputs are never stored
+    asrc[i] = a.X + (size_t)min(t0 + row, a.T - 1) * a.M + chunk * 8;
+    bsrc[i] = a.W + (size_t)min(n0 + row, a.K - 1) * a.M + chunk * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int frow = lane & 31, khalf = lane >> 5;
+  // byte offsets of this lane's fragment rows inside a tile, and their swizzle keys
+  int arow_off[2], brow_off[2], akey[2], bkey[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ra = wr * 64 + m * 32 + frow, rb = wc * 64 + m * 32 + frow;
+    arow_off[m] = ra * 128;
+    brow_off[m] = TILE_BYTES + rb * 128;
+    akey[m] = (ra >> 1) & 7;
+    bkey[m] = (rb >> 1) & 7;
+  }
+
+  for (int ks = 0; ks < ksteps; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(asrc[i] + ks * GF_BK,
+                                       (lds_ptr_t)(smem + (4 * i + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(bsrc[i] + ks * GF_BK,
+                                       (lds_ptr_t)(smem + TILE_BYTES + (4 * i + wave) * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      const int c = kq * 2 + khalf;
+      f16x8 af[2], bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        af[m] = *reinterpret_cast<const f16x8*>(smem + arow_off[m] + ((c ^ akey[m]) << 4));
+        bf[m] = *reinterpret_cast<const f16x8*>(smem + brow_off[m] + ((c ^ bkey[m]) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wc * 64 + ni * 32 + frow;
+    if (n >= a.K) continue;
+    const float f = a.colf[n];
+    float* dst;
+    int64_t ld;
+    int col;
+    bool add_res = false;
+    if (n < a.k0) {
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+    } else if (n < a.k1) {
+      dst = a.y1; ld = a.ld1; col = n - a.k0;
+    } else {
+      dst = a.y2; ld = a.ld2; col = n - a.k1;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (t < a.T) {
+          float v = acc[mi][ni][r] * f;
+          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
+          dst[(size_t)t * ld + col] = v;
+        }
+      }
+  }
+}
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace kx
+
+extern "C" size_t kx_gemm_w8_workspace_bytes(int32_t T, int32_t M, int32_t K) {
+  if (T <= 0 || M <= 0 || K <= 0) return 0;
+  return kx::align256((size_t)T * M * 2) + kx::align256((size_t)K * M * 2) + kx::align256((size_t)K * 4);
+}
+
+extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float* scales,
+                                 int32_t group_size, float* y0, int64_t ld0, float* y1,
+                                 int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
+                                 const float* residual, int64_t ldr, int32_t T, int32_t M,
+                                 int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace kx;
+  if (!X || !w || !scales || !y0 || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
+  const bool pow2 = (group_size & (group_size - 1)) == 0;
+  const bool two_pass = workspace && workspace_bytes >= kx_gemm_w8_workspace_bytes(T, M, K) &&
+                        T >= 2 * GF_BM && pow2 && group_size >= 16 && M % group_size == 0 &&
+                        M % GF_BK == 0 && ldx % 4 == 0 && ((uintptr_t)X % 16 == 0) &&
+                        ((uintptr_t)w % 16 == 0) && ((uintptr_t)workspace % 256 == 0);
+  if (!two_pass)  // short prompts: converting the whole matrix would cost more than it saves
+    return kx_gemm_w8_f32_ex(X, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1,
+                             residual, ldr, T, M, K, stream);
+  if (!y1 && !y2) { k0 = K; k1 = K; }
+  if (k0 < 0 || k1 < k0 || k1 > K) return KX_EINVAL;
+  if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = static_cast<char*>(workspace);
+  _Float16* x16 = reinterpret_cast<_Float16*>(ws);
+  _Float16* w16 = reinterpret_cast<_Float16*>(ws + align256((size_t)T * M * 2));
+  float* colf = reinterpret_cast<float*>(ws + align256((size_t)T * M * 2) + align256((size_t)K * M * 2));
+  int gs_shift = 0;
+  while ((1 << gs_shift) < group_size) ++gs_shift;
+  const int64_t n4 = (int64_t)T * (M / 4);
+  hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(2048), dim3(256), 0, s, X, ldx, x16, M, n4);
+  KX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(w8_dequant_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, w, scales, w16, colf,
+                     M, K, gs_shift);
+  KX_LAUNCH_CHECK();
+  GemmF16Args a{};
+  a.X = x16; a.W = w16; a.colf = colf; a.residual = residual;
+  a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
+  a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
+  a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
+  const int tiles_m = (T + GF_BM - 1) / GF_BM, tiles_n = (K + GF_BN - 1) / GF_BN;
+  hipLaunchKernelGGL(gemm_f16_kernel, dim3(tiles_m * tiles_n), dim3(256), 2 * GF_BM * GF_BK * 2, s, a);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}

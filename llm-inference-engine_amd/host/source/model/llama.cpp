@@ -745,8 +745,17 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   void* st = hip_->stream;
   const int32_t ql = c.q_dim_local, kl = c.kv_dim_local, hl = c.hidden_local, dim = c.dim;
   const int32_t chunk = n < kPrefillChunk ? n : kPrefillChunk;
-  // scratch: X, XN [chunk][dim]; Q, ATT [chunk][ql]; H13 [chunk][2hl]; HH [chunk][hl]
-  const size_t need = (size_t)chunk * (2 * (size_t)dim + 2 * (size_t)ql + 3 * (size_t)hl) * 4;
+  // scratch: X, XN [chunk][dim]; Q, ATT [chunk][ql]; H13 [chunk][2hl]; HH [chunk][hl]; then the
+  // fp16 workspace of the two-pass GEMM, sized for the widest matrix of a layer
+  const size_t act_bytes = (size_t)chunk * (2 * (size_t)dim + 2 * (size_t)ql + 3 * (size_t)hl) * 4;
+  const size_t act_pad = (act_bytes + 255) / 256 * 256;
+  size_t gemm_ws = 0;
+  for (size_t b : {kx_gemm_w8_workspace_bytes(chunk, dim, ql + 2 * kl),
+                   kx_gemm_w8_workspace_bytes(chunk, ql, dim),
+                   kx_gemm_w8_workspace_bytes(chunk, dim, 2 * hl),
+                   kx_gemm_w8_workspace_bytes(chunk, hl, dim)})
+    gemm_ws = b > gemm_ws ? b : gemm_ws;
+  const size_t need = act_pad + gemm_ws;
   if (need > pf_bytes_) {
     KX_RET(kx_stream_sync(st));
     dev_free(pf_);
@@ -762,6 +771,7 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   float* ATT = Q + (size_t)chunk * ql;
   float* H13 = ATT + (size_t)chunk * ql;
   float* HH = H13 + (size_t)chunk * 2 * hl;
+  void* gws = reinterpret_cast<char*>(pf_) + act_pad;
   const int gs = c.group_size;
   KX_RET(kx_stream_sync(st));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
@@ -778,24 +788,26 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
       float* krow = static_cast<float*>(k_ptr) + (size_t)p0 * kl;
       float* vrow = static_cast<float*>(v_ptr) + (size_t)p0 * kl;
       KX_RET(kx_rmsnorm_f32(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
-      KX_RET(kx_gemm_w8_f32_ex(XN, dim, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs, Q, ql,
+      KX_RET(kx_gemm_w8_f32_ws(XN, dim, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs, Q, ql,
                                krow, kl, vrow, kl, ql, ql + kl, nullptr, 0, rows, dim,
-                               lw.qkv.rows, st));
+                               lw.qkv.rows, gws, gemm_ws, st));
       KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
       KX_RET(kx_flash_attention_f32(Q, kbase, vbase, ATT, rows, c.head_local, c.kv_head_local,
                                     c.head_size, c.seq_len, p0 + rows - 1, l,
                                     1.0f / std::sqrt((float)c.head_size), 1, hip_->attn_workspace,
                                     hip_->attn_workspace_bytes, st));
-      KX_RET(kx_gemm_w8_f32_ex(ATT, ql, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs, X, dim,
-                               nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, ql, dim, st));
+      KX_RET(kx_gemm_w8_f32_ws(ATT, ql, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs, X, dim,
+                               nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, ql, dim, gws,
+                               gemm_ws, st));
       ST_RET(all_reduce(X, (size_t)rows * dim));
       KX_RET(kx_rmsnorm_f32(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
-      KX_RET(kx_gemm_w8_f32_ex(XN, dim, static_cast<const int8_t*>(lw.w13.w), lw.w13.s, gs, H13,
+      KX_RET(kx_gemm_w8_f32_ws(XN, dim, static_cast<const int8_t*>(lw.w13.w), lw.w13.s, gs, H13,
                                2 * hl, nullptr, 0, nullptr, 0, 2 * hl, 2 * hl, nullptr, 0, rows, dim,
-                               2 * hl, st));
+                               2 * hl, gws, gemm_ws, st));
       KX_RET(kx_swiglu_rows_f32(H13, 2 * hl, hl, HH, hl, rows, st));
-      KX_RET(kx_gemm_w8_f32_ex(HH, hl, static_cast<const int8_t*>(lw.w2.w), lw.w2.s, gs, X, dim,
-                               nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, hl, dim, st));
+      KX_RET(kx_gemm_w8_f32_ws(HH, hl, static_cast<const int8_t*>(lw.w2.w), lw.w2.s, gs, X, dim,
+                               nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, hl, dim, gws,
+                               gemm_ws, st));
       ST_RET(all_reduce(X, (size_t)rows * dim));
     }
   }

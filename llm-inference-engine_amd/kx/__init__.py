@@ -60,6 +60,10 @@ SIGNATURES = {
     "kx_gemm_w8_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "kx_gemm_w8_f32_ex": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
                                     C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
+    "kx_gemm_w8_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "kx_gemm_w8_f32_ws": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
+                                    C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp, _sz,
+                                    _vp]),
     "kx_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
@@ -295,12 +299,19 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
     return out.numpy(np.float32, q.shape)
 
 
-def gemm_w8(X, w, s, group_size=64):
+def gemm_w8(X, w, s, group_size=64, two_pass=False):
     K, M = w.shape
     T = X.shape[0]
     dx, dw, ds = Buf.from_numpy(X.astype(np.float32)), Buf.from_numpy(w.astype(np.int8)), \
         Buf.from_numpy(s.astype(np.float32))
     dy = Buf.zeros((T, K))
-    check(lib().kx_gemm_w8_f32(dx.ptr, dw.ptr, ds.ptr, group_size, dy.ptr, T, M, K, None),
-          "kx_gemm_w8_f32")
+    if two_pass:
+        wsb = lib().kx_gemm_w8_workspace_bytes(T, M, K)
+        ws = Buf(wsb)
+        check(lib().kx_gemm_w8_f32_ws(dx.ptr, M, dw.ptr, ds.ptr, group_size, dy.ptr, K, None, 0, None,
+                                      0, K, K, None, 0, T, M, K, ws.ptr, wsb, None),
+              "kx_gemm_w8_f32_ws")
+    else:
+        check(lib().kx_gemm_w8_f32(dx.ptr, dw.ptr, ds.ptr, group_size, dy.ptr, T, M, K, None),
+              "kx_gemm_w8_f32")
     return dy.numpy(np.float32, (T, K))

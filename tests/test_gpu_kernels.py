@@ -340,6 +340,64 @@ def test_gemm_w8_vs_oracle(T, K, M):
     assert np.sqrt((err ** 2).mean()) <= 1e-4 * np.sqrt((absum ** 2).mean())
 
 
+@pytest.mark.parametrize("T,K,M", [(256, 128, 128), (300, 200, 256), (517, 384, 1024)])
+def test_gemm_w8_two_pass_vs_oracle(T, K, M):
+    # long-prompt form: X and scale*w each rounded once to fp16 (2^-11 relative, per element)
+    rng = np.random.default_rng(T + K + M)
+    _, w, s = rand_w8(rng, K, M)
+    s = s.reshape(K, M // GS)
+    s[1] *= 1e-4          # a row of tiny scales: the per-row power-of-two factor keeps it normal
+    s[2, 1:] *= 1e-3      # small groups beside a large one in the same row
+    w[3] = 0              # an all-zero row
+    s = s.reshape(-1)
+    X = rng.standard_normal((T, M)).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    got = kx.gemm_w8(X, w, s, GS, two_pass=True)
+    sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
+    absum = np.abs(X.astype(np.float64)) @ sd.T
+    err = np.abs(got - want)
+    assert np.all(err <= 2.0 ** -10 * absum + 1e-7 * np.abs(want).max())
+    assert np.sqrt((err ** 2).mean()) <= 2e-4 * np.sqrt((absum ** 2).mean())
+    assert np.all(got[:, 3] == 0)
+
+
+def test_gemm_w8_two_pass_routing_residual_and_fallback():
+    rng = np.random.default_rng(31)
+    T, dim, kvd, S = 260, 256, 128, 300
+    K = dim + 2 * kvd
+    _, w, s = rand_w8(rng, K, dim)
+    X = rng.standard_normal((T, dim)).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    dx, dw, ds = map(kx.Buf.from_numpy, (X, w, s))
+    L = kx.lib()
+    wsb = L.kx_gemm_w8_workspace_bytes(T, dim, K)
+    assert wsb >= 2 * T * dim + 2 * K * dim + 4 * K
+    ws = kx.Buf(wsb)
+    q = kx.Buf.zeros((T, dim))
+    kc, vc = kx.Buf.zeros((S, kvd)), kx.Buf.zeros((S, kvd))
+    pos0 = 7
+    kx.check(L.kx_gemm_w8_f32_ws(dx.ptr, dim, dw.ptr, ds.ptr, GS, q.ptr, dim, kc.at(pos0 * kvd * 4),
+                                 kvd, vc.at(pos0 * kvd * 4), kvd, dim, dim + kvd, None, 0, T, dim, K,
+                                 ws.ptr, wsb, None))
+    tol = 2.0 ** -10 * (np.abs(X.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(
+        K, dim) * np.abs(w.astype(np.float64))).T) + 1e-7
+    assert np.all(np.abs(q.numpy() - want[:, :dim]) <= tol[:, :dim])
+    kcn, vcn = kc.numpy(), vc.numpy()
+    assert np.all(np.abs(kcn[pos0:pos0 + T] - want[:, dim:dim + kvd]) <= tol[:, dim:dim + kvd])
+    assert np.all(np.abs(vcn[pos0:pos0 + T] - want[:, dim + kvd:]) <= tol[:, dim + kvd:])
+    assert np.all(kcn[:pos0] == 0) and np.all(kcn[pos0 + T:] == 0)
+    R = rng.standard_normal((T, dim)).astype(np.float32)
+    y = kx.Buf.from_numpy(R)
+    kx.check(L.kx_gemm_w8_f32_ws(dx.ptr, dim, dw.ptr, ds.ptr, GS, y.ptr, dim, None, 0, None, 0, dim,
+                                 dim, y.ptr, dim, T, dim, dim, ws.ptr, wsb, None))
+    assert np.all(np.abs(y.numpy() - (want[:, :dim] + R)) <= tol[:, :dim] + 1e-6)
+    # no workspace (or a short prompt): same entry point, single-pass kernel
+    y2 = kx.Buf.zeros((T, dim))
+    kx.check(L.kx_gemm_w8_f32_ws(dx.ptr, dim, dw.ptr, ds.ptr, GS, y2.ptr, dim, None, 0, None, 0, dim,
+                                 dim, None, 0, T, dim, dim, None, 0, None))
+    assert np.all(np.abs(y2.numpy() - want[:, :dim]) <= 2.0 ** -11 * tol[:, :dim] * 2 ** 10 + 1e-7)
+
+
 def test_gemm_w8_small_T_and_odd_group_fall_back_to_gemv_rows():
     rng = np.random.default_rng(2)
     x, w, s = rand_w8(rng, 96, 192)
