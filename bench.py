@@ -58,7 +58,7 @@ def prefill_kernels(kx, shape, tp, T=4096):
     out = kx.Buf(T * H * hs * 4)
     for buf, n, seed in ((q, T * H * hs, 3), (kc, T * kvd, 4), (vc, T * kvd, 5)):
         kx.check(L.kx_fill_hash_f32(buf.ptr, 1, n, n, 0, 0, seed, -1.0, 1.0, st.ptr), "fill")
-    wsb = L.kx_attn_workspace_bytes(H, hs)
+    wsb = max(L.kx_attn_workspace_bytes(H, hs), L.kx_flash_attention_workspace_bytes(T - 1, KVH, hs))
     ws = kx.Buf.zeros(wsb, np.uint8)
     scale = float(1.0 / np.sqrt(hs))
 

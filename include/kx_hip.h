@@ -197,6 +197,11 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
  * 0..that position when causal, 0..pos otherwise; kv head = h / (head_num/kv_head_num).
  * Tq == 1 is kx_mha_decode_f32.  Tq > 1 runs the MFMA kernel (fp16 operands, fp32 softmax and
  * accumulation). */
+/* Workspace for Tq > 1 that lets the kernel work from fp16 copies of the layer's K/V rows 0..pos
+ * (made once per call).  The first 16 KiB are left untouched, so the decode workspace, grown to
+ * this size, can serve both.  With a smaller workspace each workgroup converts the fp32 rows it
+ * stages (slower, same results up to fp16 rounding order). */
+size_t kx_flash_attention_workspace_bytes(int32_t pos, int32_t kv_head_num, int32_t head_size);
 int kx_flash_attention_f32(const float* query, const float* key_cache, const float* value_cache,
                            float* out, int32_t Tq, int32_t head_num, int32_t kv_head_num,
                            int32_t head_size, int32_t seq_len, int32_t pos, int32_t layer_idx,

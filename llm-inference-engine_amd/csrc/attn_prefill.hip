@@ -17,6 +17,9 @@
 //     the B operand of the second product: probabilities never leave registers, and the
 //     online-softmax state (running max, running sum, rescale factor) is one value per lane.
 //   - fp32 everywhere outside the two MFMA operand roundings (Q*scale, K, V, P to fp16).
+//   - with a workspace of kx_flash_attention_workspace_bytes() the layer's K/V rows are converted
+//     to fp16 once per call (K row-major, V transposed) and the tiles are staged by 16-byte
+//     copies; without it each workgroup converts the fp32 rows it stages.
 #include <math.h>
 
 #include "kx_common.hpp"
@@ -24,7 +27,48 @@
 namespace kx {
 
 constexpr int FA_KV = 64;       // keys per tile
-constexpr int FA_VT_ROW = 68;   // halves per padded V^T row (64 keys + 4)
+constexpr int FA_VT_ROW = 68;   // halves per padded V^T row (64 keys + 4), fp32-source path
+constexpr int FA_VT_ROW16 = 72; // same for the fp16-source path (16-byte aligned rows)
+constexpr size_t FA_WS_SKIP = 16384;  // head of the workspace left alone (decode arrival tickets)
+
+// fp16 copies of one layer's K and V rows 0..pos, made once per call when the caller provides the
+// workspace: K16 [kvh][S_pad][HS] row-major; V16T [kvh][HS][S_pad] transposed, and inside every
+// block of 16 keys position 8h+4g+e holds key 8g+4h+e -- the order in which the score registers
+// of the S^T tile come out -- so the V^T fragment of the second product is one 16-byte read.
+__device__ __forceinline__ int fa_key_of_pos(int p) {  // swaps bits 2 and 3; its own inverse
+  return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1);
+}
+
+template <int HS>
+__global__ __launch_bounds__(256) void kv_to_f16_kernel(const float* __restrict__ kc,
+                                                        const float* __restrict__ vc,
+                                                        _Float16* __restrict__ k16,
+                                                        _Float16* __restrict__ v16t, int kv_dim,
+                                                        int pos, int s_pad) {
+  constexpr int VROW = HS + 2;  // halves per LDS row: odd word stride for the column gathers
+  __shared__ _Float16 vt[FA_KV * VROW];
+  const int tid = threadIdx.x;
+  const int key0 = blockIdx.x * FA_KV, kvh = blockIdx.y;
+  for (int item = tid; item < FA_KV * (HS / 4); item += 256) {
+    const int key = item / (HS / 4), d4 = (item % (HS / 4)) * 4;
+    const size_t src = (size_t)min(key0 + key, pos) * kv_dim + (size_t)kvh * HS + d4;
+    const f32x4 kv = *reinterpret_cast<const f32x4*>(kc + src);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(vc + src);
+    f16x4 h;
+    h[0] = (_Float16)kv.x; h[1] = (_Float16)kv.y; h[2] = (_Float16)kv.z; h[3] = (_Float16)kv.w;
+    *reinterpret_cast<f16x4*>(k16 + ((size_t)kvh * s_pad + key0 + key) * HS + d4) = h;
+    _Float16* row = vt + key * VROW + d4;
+    row[0] = (_Float16)vv.x; row[1] = (_Float16)vv.y; row[2] = (_Float16)vv.z; row[3] = (_Float16)vv.w;
+  }
+  __syncthreads();
+  for (int item = tid; item < HS * (FA_KV / 8); item += 256) {
+    const int d = item / (FA_KV / 8), c = item % (FA_KV / 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = vt[fa_key_of_pos(8 * c + j) * VROW + d];
+    *reinterpret_cast<f16x8*>(v16t + ((size_t)kvh * HS + d) * s_pad + key0 + 8 * c) = o;
+  }
+}
 
 struct FaArgs {
   const float* q;   // [Tq][H][HS]
@@ -35,15 +79,21 @@ struct FaArgs {
   int32_t hpb;      // query heads per workgroup (divides kv_mul)
   int32_t qsubs;    // 32-row sub-blocks per workgroup
   float scale;
+  const _Float16* k16;   // fp16 copies (see kv_to_f16_kernel), or null
+  const _Float16* v16t;
+  int32_t s_pad;
 };
 
-template <int HS>
+// F16SRC: K/V tiles come from the fp16 copies (16-byte copies into LDS, no conversion) instead of
+// the fp32 cache rows.
+template <int HS, bool F16SRC>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   constexpr int K_ROW = HS + 8;         // halves per padded K row
   constexpr int KS = HS / 16;           // 16-dim MFMA steps of Q.K
   constexpr int DT = HS / 32;           // 32-dim output tiles
   constexpr int K_TILE = FA_KV * K_ROW; // halves
-  constexpr int V_TILE = HS * FA_VT_ROW;
+  constexpr int VT_ROW = F16SRC ? FA_VT_ROW16 : FA_VT_ROW;
+  constexpr int V_TILE = HS * VT_ROW;
   constexpr int BUF = K_TILE + V_TILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* lds = reinterpret_cast<_Float16*>(smem);
@@ -70,6 +120,9 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   const int ntiles = max_key / FA_KV + 1;
 
   // ---- Q fragment (B operand): lane (q row, half) holds Q[row][16ks + 8half + j] * scale ----
+  // scores are kept in the log2 domain: Q is scaled by softmax_scale * log2(e)
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float qscale = a.scale * kLog2e;
   f16x8 qf[KS];
   {
     const bool valid = my_row < a.Tq;
@@ -81,14 +134,14 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
         v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
         v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
       }
-      qf[ks][0] = (_Float16)(v0.x * a.scale);
-      qf[ks][1] = (_Float16)(v0.y * a.scale);
-      qf[ks][2] = (_Float16)(v0.z * a.scale);
-      qf[ks][3] = (_Float16)(v0.w * a.scale);
-      qf[ks][4] = (_Float16)(v1.x * a.scale);
-      qf[ks][5] = (_Float16)(v1.y * a.scale);
-      qf[ks][6] = (_Float16)(v1.z * a.scale);
-      qf[ks][7] = (_Float16)(v1.w * a.scale);
+      qf[ks][0] = (_Float16)(v0.x * qscale);
+      qf[ks][1] = (_Float16)(v0.y * qscale);
+      qf[ks][2] = (_Float16)(v0.z * qscale);
+      qf[ks][3] = (_Float16)(v0.w * qscale);
+      qf[ks][4] = (_Float16)(v1.x * qscale);
+      qf[ks][5] = (_Float16)(v1.y * qscale);
+      qf[ks][6] = (_Float16)(v1.z * qscale);
+      qf[ks][7] = (_Float16)(v1.w * qscale);
     }
   }
 
@@ -99,13 +152,41 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   constexpr int MAXT = 256;  // fewest threads a launch uses
   constexpr int K_PER = (K_ITEMS + MAXT - 1) / MAXT;
   constexpr int V_PER = (V_ITEMS + MAXT - 1) / MAXT;
-  f32x4 kreg[K_PER];
-  f32x4 vreg[V_PER][4];
+  // fp16 source: K item = (key, 8-dim chunk), V item = (dim, 8-key chunk), 16 bytes each
+  constexpr int K16_ITEMS = FA_KV * (HS / 8);
+  constexpr int V16_ITEMS = HS * (FA_KV / 8);
+  constexpr int K16_PER = (K16_ITEMS + MAXT - 1) / MAXT;
+  constexpr int V16_PER = (V16_ITEMS + MAXT - 1) / MAXT;
+  f32x4 kreg[F16SRC ? 1 : K_PER];
+  f32x4 vreg[F16SRC ? 1 : V_PER][4];
+  i32x4 kreg16[F16SRC ? K16_PER : 1];
+  i32x4 vreg16[F16SRC ? V16_PER : 1];
   const float* kbase = a.kc + (size_t)kvh * HS;
   const float* vbase = a.vc + (size_t)kvh * HS;
+  const _Float16* k16base = F16SRC ? a.k16 + (size_t)kvh * a.s_pad * HS : nullptr;
+  const _Float16* v16base = F16SRC ? a.v16t + (size_t)kvh * HS * a.s_pad : nullptr;
 
   auto load_tile = [&](int t) {
     const int key0 = t * FA_KV;
+    if constexpr (F16SRC) {
+#pragma unroll
+      for (int i = 0; i < K16_PER; ++i) {
+        const int item = tid + i * nthreads;
+        if (item < K16_ITEMS) {
+          const int key = item / (HS / 8), ch = item % (HS / 8);
+          kreg16[i] = *reinterpret_cast<const i32x4*>(k16base + (size_t)(key0 + key) * HS + 8 * ch);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < V16_PER; ++i) {
+        const int item = tid + i * nthreads;
+        if (item < V16_ITEMS) {
+          const int d = item / (FA_KV / 8), ch = item % (FA_KV / 8);
+          vreg16[i] = *reinterpret_cast<const i32x4*>(v16base + (size_t)d * a.s_pad + key0 + 8 * ch);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < K_PER; ++i) {
       const int item = tid + i * nthreads;
@@ -130,6 +211,25 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   auto store_tile = [&](int buf) {
     _Float16* Kl = lds + buf * BUF;
     _Float16* Vl = Kl + K_TILE;
+    if constexpr (F16SRC) {
+#pragma unroll
+      for (int i = 0; i < K16_PER; ++i) {
+        const int item = tid + i * nthreads;
+        if (item < K16_ITEMS) {
+          const int key = item / (HS / 8), ch = item % (HS / 8);
+          *reinterpret_cast<i32x4*>(Kl + key * K_ROW + 8 * ch) = kreg16[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < V16_PER; ++i) {
+        const int item = tid + i * nthreads;
+        if (item < V16_ITEMS) {
+          const int d = item / (FA_KV / 8), ch = item % (FA_KV / 8);
+          *reinterpret_cast<i32x4*>(Vl + d * VT_ROW + 8 * ch) = vreg16[i];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < K_PER; ++i) {
       const int item = tid + i * nthreads;
@@ -156,7 +256,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
           f16x4 h;
           h[0] = (_Float16)vals[d][0]; h[1] = (_Float16)vals[d][1];
           h[2] = (_Float16)vals[d][2]; h[3] = (_Float16)vals[d][3];
-          *reinterpret_cast<f16x4*>(Vl + (4 * dg + d) * FA_VT_ROW + 4 * kg) = h;
+          *reinterpret_cast<f16x4*>(Vl + (4 * dg + d) * VT_ROW + 4 * kg) = h;
         }
       }
     }
@@ -168,7 +268,6 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  constexpr float kLog2e = 1.4426950408889634f;
 
   load_tile(0);
   store_tile(0);
@@ -215,14 +314,14 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
       const float m_new = fmaxf(m_run, mx);
       // a row whose keys are all masked so far keeps m = -inf; guard the inf - inf
       const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = exp2f((m_run - m_use) * kLog2e);
+      const float alpha = exp2f(m_run - m_use);
       m_run = m_new;
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = exp2f((s[kt][r] - m_use) * kLog2e);
+          const float p = exp2f(s[kt][r] - m_use);
           s[kt][r] = p;
           psum += p;
         }
@@ -242,15 +341,25 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
           f16x8 pf;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (_Float16)s[kt][8 * st + j];
-          const _Float16* vp = Vl + qcol * FA_VT_ROW + kt * 32 + 16 * st + 4 * half;
+          if constexpr (F16SRC) {
+            // keys are stored in score-register order: the fragment is one 16-byte read
+            const _Float16* vp = Vl + qcol * VT_ROW + kt * 32 + 16 * st + 8 * half;
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const f16x4 lo = *reinterpret_cast<const f16x4*>(vp + dt * 32 * FA_VT_ROW);
-            const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + dt * 32 * FA_VT_ROW + 8);
-            f16x8 vf;
-            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt) {
+              const f16x8 vf = *reinterpret_cast<const f16x8*>(vp + dt * 32 * VT_ROW);
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+          } else {
+            const _Float16* vp = Vl + qcol * VT_ROW + kt * 32 + 16 * st + 4 * half;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const f16x4 lo = *reinterpret_cast<const f16x4*>(vp + dt * 32 * VT_ROW);
+              const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + dt * 32 * VT_ROW + 8);
+              f16x8 vf;
+              vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+              vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+            }
           }
         }
     }
@@ -274,22 +383,50 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   }
 }
 
-template <int HS>
-static int launch_prefill(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
+template <int HS, bool F16SRC>
+static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
+  constexpr int vt_row = F16SRC ? FA_VT_ROW16 : FA_VT_ROW;
+  constexpr size_t lds = 2 * (size_t)(FA_KV * (HS + 8) + HS * vt_row) * 2;
   static bool raised = false;
   if (lds > 64 * 1024 && !raised) {
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS>),
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, F16SRC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = true;
   }
   const dim3 grid(kvh * (a.kv_mul / a.hpb), qblocks);
-  hipLaunchKernelGGL(attn_prefill_kernel<HS>, grid, dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((attn_prefill_kernel<HS, F16SRC>), grid, dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
 
+template <int HS>
+static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* workspace,
+                          size_t workspace_bytes, hipStream_t s) {
+  const int s_pad = (a.pos / FA_KV + 1) * FA_KV;
+  const size_t half_bytes = (size_t)kvh * s_pad * HS * 2;
+  if (workspace && workspace_bytes >= FA_WS_SKIP + 2 * half_bytes) {
+    char* ws = static_cast<char*>(workspace) + FA_WS_SKIP;
+    _Float16* k16 = reinterpret_cast<_Float16*>(ws);
+    _Float16* v16t = reinterpret_cast<_Float16*>(ws + half_bytes);
+    hipLaunchKernelGGL(kv_to_f16_kernel<HS>, dim3(s_pad / FA_KV, kvh), dim3(256), 0, s, a.kc, a.vc,
+                       k16, v16t, a.kv_dim, a.pos, s_pad);
+    KX_LAUNCH_CHECK();
+    a.k16 = k16;
+    a.v16t = v16t;
+    a.s_pad = s_pad;
+    return launch_prefill_kernel<HS, true>(a, kvh, threads, qblocks, s);
+  }
+  return launch_prefill_kernel<HS, false>(a, kvh, threads, qblocks, s);
+}
+
 }  // namespace kx
+
+extern "C" size_t kx_flash_attention_workspace_bytes(int32_t pos, int32_t kv_head_num,
+                                                     int32_t head_size) {
+  if (pos < 0 || kv_head_num <= 0 || head_size <= 0) return 0;
+  const size_t s_pad = (size_t)(pos / kx::FA_KV + 1) * kx::FA_KV;
+  return kx::FA_WS_SKIP + 2 * (size_t)kv_head_num * s_pad * head_size * 2;
+}
 
 extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache,
                                       const float* value_cache, float* out, int32_t Tq,
@@ -336,8 +473,8 @@ extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache
   const int qblocks = (Tq + 32 * qsubs - 1) / (32 * qsubs);
   hipStream_t s = (hipStream_t)stream;
   switch (head_size) {
-    case 32: return launch_prefill<32>(a, kv_head_num, threads, qblocks, s);
-    case 64: return launch_prefill<64>(a, kv_head_num, threads, qblocks, s);
-    default: return launch_prefill<128>(a, kv_head_num, threads, qblocks, s);
+    case 32: return launch_prefill<32>(a, kv_head_num, threads, qblocks, workspace, workspace_bytes, s);
+    case 64: return launch_prefill<64>(a, kv_head_num, threads, qblocks, workspace, workspace_bytes, s);
+    default: return launch_prefill<128>(a, kv_head_num, threads, qblocks, workspace, workspace_bytes, s);
   }
 }

@@ -25,7 +25,7 @@ struct HipConfig {
 
   // Creates both streams and the event pair on the current device.  Returns 0 or a C-ABI code.
   int create_streams();
-  int reserve_attn_workspace(int head_num, int head_size, int seq_len);
+  int reserve_attn_workspace(int head_num, int kv_head_num, int head_size, int seq_len);
 };
 // The registry typedefs keep the reference's spelling (kernels_interface.h:9-54).
 using CudaConfig = HipConfig;

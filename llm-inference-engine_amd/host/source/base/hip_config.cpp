@@ -21,12 +21,15 @@ int HipConfig::create_streams() {
   return 0;
 }
 
-int HipConfig::reserve_attn_workspace(int head_num, int head_size, int seq_len) {
+int HipConfig::reserve_attn_workspace(int head_num, int kv_head_num, int head_size, int seq_len) {
   size_t need = kx_attn_workspace_bytes(head_num, head_size);
   // the generic attention kernel wants a [head_num][seq_len] score scratch
   // behind the ticket words that head the workspace
   const size_t score = 16384 + (size_t)head_num * (size_t)seq_len * sizeof(float);
   if (score > need) need = score;
+  // and the flash-attention prefill wants fp16 copies of up to seq_len K/V rows of a layer
+  const size_t fa = kx_flash_attention_workspace_bytes(seq_len - 1, kv_head_num, head_size);
+  if (fa > need) need = fa;
   if (need <= attn_workspace_bytes) return 0;
   if (attn_workspace) kx_free(attn_workspace);
   attn_workspace = nullptr;

@@ -145,7 +145,7 @@ static int attn_common(bool flash, const float* q, const float* kc, const float*
                        int32_t layer_idx, int32_t pos, int32_t tq, float* out_host) {
   auto cfg = std::make_shared<kernel::CudaConfig>();
   if (int rc = cfg->create_streams()) return rc;
-  if (int rc = cfg->reserve_attn_workspace(head_num, head_size, seq_len)) return rc;
+  if (int rc = cfg->reserve_attn_workspace(head_num, head_num / kv_mul, head_size, seq_len)) return rc;
   const int32_t kv_dim = head_num / kv_mul * head_size;
   const base::DataType f32 = base::DataType::kDataTypeFp32;
   tensor::Tensor key = dev_from_host(f32, {layers, seq_len, kv_dim}, kc);

@@ -140,7 +140,7 @@ base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
   quant_ = cfg_.group_size > 0;
   hip_ = std::make_shared<kernel::CudaConfig>();
   KX_RET(hip_->create_streams());  // llama3.cpp:124-128
-  KX_RET(hip_->reserve_attn_workspace(cfg_.head_local, cfg_.head_size, cfg_.seq_len));
+  KX_RET(hip_->reserve_attn_workspace(cfg_.head_local, cfg_.kv_head_local, cfg_.head_size, cfg_.seq_len));
   kernel::model_knobs().rope_variant = cfg_.rope_variant;
   kernel::model_knobs().rms_eps = cfg_.rms_eps;
 

@@ -66,6 +66,7 @@ SIGNATURES = {
                                     _vp]),
     "kx_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
+    "kx_flash_attention_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _sz, _vp]),
     "kx_mha_decode_dpos_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
@@ -281,7 +282,7 @@ def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspa
 
 
 def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx, softmax_scale=None,
-                    is_causal=True):
+                    is_causal=True, f16_copies=True):
     L, S, kv_dim = kc.shape
     q = np.ascontiguousarray(q, np.float32).reshape(-1, head_num, head_size)
     Tq = q.shape[0]
@@ -291,6 +292,10 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
         Buf.from_numpy(vc.astype(np.float32))
     out = Buf.zeros(q.size)
     wsb = max(lib().kx_attn_workspace_bytes(head_num, head_size), 16384 + head_num * S * 4)
+    if f16_copies:  # large enough for the fp16 K/V copies of the prefill path
+        wsb = max(wsb, lib().kx_flash_attention_workspace_bytes(pos, kv_head_num, head_size))
+    else:
+        wsb = min(wsb, lib().kx_flash_attention_workspace_bytes(pos, kv_head_num, head_size) - 1)
     ws = Buf.zeros(wsb, np.uint8)
     check(lib().kx_flash_attention_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, Tq, head_num, kv_head_num,
                                        head_size, S, pos, layer_idx, softmax_scale,

@@ -464,9 +464,28 @@ def test_flash_attention_vs_oracle(H, KVH, hs, S, pos, Tq, causal):
     vc = rng.standard_normal((L, S, KVH * hs)).astype(np.float32)
     q = rng.standard_normal((Tq, H, hs)).astype(np.float32)
     want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, layer, is_causal=causal, threads=8)
-    got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, layer, is_causal=causal)
-    np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
-    assert np.sqrt(((got - want) ** 2).mean()) <= 4e-4
+    # both staging forms: fp16 copies of K/V made once in the workspace, and per-tile conversion
+    for f16_copies in (True, False):
+        got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, layer, is_causal=causal,
+                                 f16_copies=f16_copies)
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
+        assert np.sqrt(((got - want) ** 2).mean()) <= 4e-4
+
+
+def test_flash_attention_nan_past_pos_is_never_read():
+    # cache rows after `pos` are poison: neither the fp16 pre-pass nor the tiles may touch them
+    rng = np.random.default_rng(77)
+    H, KVH, hs, S, pos, Tq = 8, 2, 128, 256, 200, 140
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal((Tq, H, hs)).astype(np.float32)
+    want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, 0, threads=8)
+    kc[0, pos + 1:] = np.nan
+    vc[0, pos + 1:] = np.nan
+    for f16_copies in (True, False):
+        got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0, f16_copies=f16_copies)
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
 
 
 def test_flash_attention_forced_rescale_and_last_row_equals_decode():
