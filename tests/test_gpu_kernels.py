@@ -201,6 +201,45 @@ def test_mha_decode_vs_oracle(H, KVH, hs, S, pos):
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
 
 
+def test_mha_decode_long_context_several_tiles_per_wave():
+    # past 8192 keys per kv head a wave walks several tiles with the next one prefetched
+    rng = np.random.default_rng(90)
+    H, KVH, hs, S, pos = 8, 1, 128, 9100, 9000
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_mha_decode_device_position_one_workspace_many_launches():
+    # the form used under graph replay: the grid is sized for the longest context, the position
+    # is read from device memory, and every launch shares one workspace whose arrival counters
+    # must come back to zero whatever the number of splits was
+    rng = np.random.default_rng(91)
+    H, KVH, hs, S = 32, 8, 128, 4096
+    kvd = KVH * hs
+    kc = rng.standard_normal((1, S, kvd)).astype(np.float32)
+    vc = rng.standard_normal((1, S, kvd)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    L = kx.lib()
+    dq, dk, dv = kx.Buf.from_numpy(q), kx.Buf.from_numpy(kc), kx.Buf.from_numpy(vc)
+    out = kx.Buf.zeros(H * hs)
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    pos_dev = kx.Buf.zeros(1, np.int32)
+    for pos in (5, 4000, 63, 64, 2047, 100, 4095, 0):
+        pos_dev.upload(np.array([pos], np.int32))
+        kx.check(L.kx_mha_decode_dpos_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H,
+                                          H // KVH, hs, kvd, S, 0, ws.ptr, wsb, None))
+        kx.sync()
+        want = kxo.mha(pos, H, 0, S, kvd, H // KVH, hs, q, kc, vc).reshape(H, hs)
+        np.testing.assert_allclose(out.numpy(np.float32, (H, hs)), want, rtol=0, atol=2e-5,
+                                   err_msg=f"pos={pos}")
+    assert not ws.numpy(np.uint8, (wsb,))[:16384].any()  # tickets are back at zero
+
+
 def test_mha_decode_forced_rescale_and_no_workspace():
     # one key far above the rest late in the sequence forces the online-softmax rescale branch;
     # with no workspace the kernel must fall back to a single split and still be right
