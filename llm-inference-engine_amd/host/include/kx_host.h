@@ -33,6 +33,11 @@ int kxm_shard_plan(int32_t dim, int32_t hidden_dim, int32_t head_num, int32_t kv
                    int32_t tp_size, int32_t tp_rank, int32_t* slices28, int32_t* carries_residual);
 int kxm_comm_unique_id(void* id128);
 int kxm_init_comm(void* model, const void* id128);
+/* Test rig: tensor-parallel ranks as objects of one process (one host thread per rank), summing
+ * through a host rendezvous instead of RCCL; eager launches only. */
+void* kxm_loopback_create(int32_t ranks);
+void kxm_loopback_destroy(void* group);
+int kxm_join_loopback(void* model, void* group);
 int kxm_forward_layers(void* model, int32_t token, int32_t pos, float* logits_host);
 int kxm_set_state(void* model, int32_t token, int32_t pos);
 int kxm_step_logits(void* model, int32_t token, int32_t pos, float* logits_host);

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "base/kv_cache_manager.h"
+#include "base/loopback_comm.h"
 #include "base/rccl_handler.h"
 #include "op/flash_attention.h"
 #include "op/matmul.h"
@@ -85,6 +86,9 @@ class LlamaModel {
   base::Status read_weight(const std::string& name, int32_t layer, void* host_out, size_t bytes) const;
 
   base::Status init_comm(const base::CommUniqueId* id);
+  // Test rig: the ranks of a tensor-parallel model as objects of one process (one thread each),
+  // summing through a host rendezvous instead of RCCL.  Eager launches only.
+  void join_loopback(std::shared_ptr<base::LoopbackGroup> group) { loop_ = std::move(group); }
 
   // ---- reference-structured path ----
   base::Status forward_layers(int32_t token, int32_t pos, float* logits_host);
@@ -144,6 +148,7 @@ class LlamaModel {
   TransformerConfig cfg_;
   bool quant_ = false;
   bool comm_ready_ = false;
+  std::shared_ptr<base::LoopbackGroup> loop_;
   std::shared_ptr<kernel::CudaConfig> hip_;
   std::vector<LayerWeights> layers_;
   Linear cls_;

@@ -80,6 +80,18 @@ int kxm_init_comm(void* m, const void* id128) {
   if (id128) std::memcpy(id.data(), id128, id.size());
   return done(M(m)->init_comm(id128 ? &id : nullptr));
 }
+void* kxm_loopback_create(int32_t ranks) {
+  if (ranks < 1) return nullptr;
+  return new std::shared_ptr<base::LoopbackGroup>(std::make_shared<base::LoopbackGroup>(ranks));
+}
+void kxm_loopback_destroy(void* group) {
+  delete static_cast<std::shared_ptr<base::LoopbackGroup>*>(group);
+}
+int kxm_join_loopback(void* m, void* group) {
+  if (!m || !group) return -1;
+  M(m)->join_loopback(*static_cast<std::shared_ptr<base::LoopbackGroup>*>(group));
+  return 0;
+}
 int kxm_forward_layers(void* m, int32_t token, int32_t pos, float* logits) {
   return done(M(m)->forward_layers(token, pos, logits));
 }

@@ -624,6 +624,7 @@ base::Status LlamaModel::gemv(const Linear& l, int mode, const float* x, const f
 }
 
 base::Status LlamaModel::all_reduce(float* buf, size_t count) {
+  if (loop_) return loop_->all_reduce(cfg_.tp_rank, buf, count, hip_->stream);
   if (cfg_.tp_size <= 1 && !comm_ready_) return base::error::Success();
   if (!comm_ready_) return base::error::InternalError("tensor-parallel model without init_comm()");
   auto comm = base::RcclHandler::get_instance();
@@ -695,6 +696,8 @@ base::Status LlamaModel::decode(int32_t steps, bool use_graph) {
   if (pos + steps > cfg_.seq_len)
     return base::error::InvalidArgument("decode would run past seq_len");
   void* st = hip_->stream;
+  if (use_graph && loop_)
+    return base::error::InvalidArgument("the loopback communicator cannot be captured into a graph");
   if (use_graph) {
     if (!graph_) {
       // one eager step first: lazy per-kernel setup (e.g. raising a kernel's LDS limit) must

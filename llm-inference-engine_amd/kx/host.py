@@ -145,6 +145,9 @@ class Model:
         buf = np.frombuffer(id128, np.uint8).copy() if id128 is not None else None
         hcheck(hlib().kxm_init_comm(self.h, _p(buf)), "kxm_init_comm")
 
+    def join_loopback(self, group):
+        hcheck(hlib().kxm_join_loopback(self.h, group), "kxm_join_loopback")
+
     def forward_layers(self, token, pos):
         out = np.empty(self.cfg.vocab_size, np.float32)
         hcheck(hlib().kxm_forward_layers(self.h, int(token), int(pos), _p(out)), "kxm_forward_layers")
@@ -217,6 +220,20 @@ def shard_plan(dim, hidden_dim, head_num, kv_head_num, tp_size, tp_rank):
         raise ValueError("geometry does not divide over tp_size ranks")
     plan = {n: tuple(out[4 * i:4 * i + 4]) for i, n in enumerate(SHARD_NAMES)}
     return plan, bool(res.value)
+
+
+def loopback_create(ranks):
+    L = hlib()
+    L.kxm_loopback_create.restype = C.c_void_p
+    L.kxm_loopback_create.argtypes = [_i32]
+    L.kxm_join_loopback.argtypes = [_vp, _vp]
+    L.kxm_loopback_destroy.argtypes = [_vp]
+    L.kxm_loopback_destroy.restype = None
+    return L.kxm_loopback_create(ranks)
+
+
+def loopback_destroy(group):
+    hlib().kxm_loopback_destroy(group)
 
 
 def comm_unique_id():

@@ -277,3 +277,78 @@ def test_fused_path_refuses_fp32_weights():
     m.init_synthetic(1)
     with pytest.raises(kx.KxError):
         m.step_logits(1, 0)
+
+
+# ---------------- tensor-parallel token loop on one GPU ---------------------------------------------
+def _run_ranks(models, fn):
+    """Runs fn(rank, model) on one host thread per rank (ctypes releases the GIL) and returns the
+    results in rank order; the ranks meet inside the loopback all-reduce."""
+    import threading
+    out, err = [None] * len(models), []
+
+    def work(r):
+        try:
+            out[r] = fn(r, models[r])
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(len(models))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not err, err
+    assert all(o is not None for o in out), "a rank did not finish"
+    return out
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_tensor_parallel_ranks_equal_single_rank(tp):
+    # Every rank of a TP model as an object of this process, the all-reduces through a host
+    # rendezvous: column/row shards, the residual owner and the two reduces per layer must
+    # reproduce the unsharded model (row-parallel sums are re-associated: 1e-4 of the logit range).
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    seq_len = 320
+    rng = np.random.default_rng(5)
+    toks = rng.integers(0, 700, 10).astype(np.int32)
+    one = host.Model(seq_len=seq_len, group_size=GS, **shape)
+    one.init_synthetic(21)
+    want = np.stack([one.step_logits(int(t), p) for p, t in enumerate(toks)])
+    group = host.loopback_create(tp)
+    ranks = [host.Model(seq_len=seq_len, group_size=GS, tp_size=tp, tp_rank=r, **shape)
+             for r in range(tp)]
+    for m in ranks:
+        m.init_synthetic(21)
+        m.join_loopback(group)
+    got = _run_ranks(ranks, lambda r, m: np.stack([m.step_logits(int(t), p)
+                                                   for p, t in enumerate(toks)]))
+    for r in range(tp):
+        np.testing.assert_array_equal(got[r], got[0])   # every rank ends with the same logits
+    assert np.abs(got[0] - want).max() <= 1e-4 * np.abs(want).max()
+    # each rank's cache rows are its kv heads' columns of the unsharded cache
+    kvl = ranks[0].kv_dim_local
+    for layer in range(2):
+        kf, vf = one.read_kv(layer, len(toks))
+        for r, m in enumerate(ranks):
+            k, v = m.read_kv(layer, len(toks))
+            np.testing.assert_allclose(k, kf[:, r * kvl:(r + 1) * kvl], rtol=0, atol=1e-4 * np.abs(kf).max())
+            np.testing.assert_allclose(v, vf[:, r * kvl:(r + 1) * kvl], rtol=0, atol=1e-4 * np.abs(vf).max())
+    # batched prompt pass under TP (GEMMs, flash attention on the local heads, reduces of whole
+    # row blocks), long enough for the two-pass GEMM, then eager greedy steps
+    prompt = rng.integers(0, 700, 280).astype(np.int32)
+    ref_last = one.prefill(prompt)
+    one.decode(6, use_graph=False)
+    ref_hist = one.history(len(prompt) + 7)
+    outs = _run_ranks(ranks, lambda r, m: (m.prefill(prompt), m.decode(6, use_graph=False),
+                                           m.history(len(prompt) + 7)))
+    for r in range(tp):
+        assert np.abs(outs[r][0] - ref_last).max() <= 2e-3 * np.abs(ref_last).max()
+        np.testing.assert_array_equal(outs[r][2], outs[0][2])
+    order = np.argsort(ref_last)
+    if ref_last[order[-1]] - ref_last[order[-2]] > 1e-2 * np.abs(ref_last).max():
+        assert outs[0][2][len(prompt)] == ref_hist[len(prompt)]
+    with pytest.raises(kx.KxError):
+        ranks[0].decode(1, use_graph=True)   # a host rendezvous cannot be captured
+    for m in ranks:
+        m.close()
+    host.loopback_destroy(group)
