@@ -41,7 +41,10 @@ def test_gemv_w8_golden(golden, name):
 
 @pytest.mark.parametrize("K,M", [(1, 64), (3, 64), (7, 192), (64, 1024), (130, 2048), (512, 2048),
                                  (33, 3584), (256, 4096), (17, 14336), (8, 18944), (5, 28672),
-                                 (2048, 2048)])
+                                 (2048, 2048),
+                                 # per-rank shapes of the tensor-parallel configs: 8B at TP=8
+                                 # (Wo, W2), Qwen2.5-7B at TP=4 (Wo, W2), 70B at TP=8 (W2)
+                                 (4096, 512), (4096, 1792), (3584, 896), (3584, 4736), (1024, 3584)])
 def test_gemv_w8_vs_oracle(K, M):
     rng = np.random.default_rng(K * 100003 + M)
     x, w, s = rand_w8(rng, K, M)
@@ -91,7 +94,7 @@ def test_gemv_w8_ex_routing_bias_residual():
                   + 1e-6)
 
 
-@pytest.mark.parametrize("H,M", [(256, 512), (1000, 2048), (344, 4096)])
+@pytest.mark.parametrize("H,M", [(256, 512), (1000, 2048), (344, 4096), (1792, 4096), (4736, 3584)])
 def test_gemv_w8_swiglu(H, M):
     rng = np.random.default_rng(H)
     x, w, s = rand_w8(rng, 2 * H, M)
