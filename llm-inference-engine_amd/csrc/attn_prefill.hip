@@ -298,40 +298,53 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
       }
       // ---- mask + online softmax (one query row per lane; the other half-wave holds the
       //      other 32 keys of the same row) ----
-      float mx = -INFINITY;
-      const bool need_mask = key0 + FA_KV - 1 > my_pos;
+      // only the tiles on the diagonal (or at the end of the cache) hold keys some row must not
+      // see: a wave-uniform test keeps the masking code off the common path
+      if (__any(key0 + FA_KV - 1 > my_pos)) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (need_mask) {
+          for (int r = 0; r < 16; ++r) {
             const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (key > my_pos) s[kt][r] = -INFINITY;
           }
-          mx = fmaxf(mx, s[kt][r]);
-        }
-      mx = fmaxf(mx, lane_xor32(mx));
-      const float m_new = fmaxf(m_run, mx);
-      // a row whose keys are all masked so far keeps m = -inf; guard the inf - inf
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = exp2f(m_run - m_use);
-      m_run = m_new;
-      float psum = 0.f;
+      }
+      float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(s[kt][r] - m_use);
-          s[kt][r] = p;
-          psum += p;
-        }
-      l_run = l_run * alpha + psum;
-      if (__any(alpha != 1.0f)) {
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, lane_xor32(mx));
+      // Lazy running max: the reference point of the exponentials only moves when some row's
+      // new maximum exceeds the old one by more than 2^kLazy (scores are in the log2 domain).
+      // Softmax does not depend on the reference point; keeping it makes alpha = 1 and skips the
+      // rescale of the whole output tile, and p <= 2^kLazy stays far inside fp16 range.
+      constexpr float kLazy = 8.0f;
+      if (__any(mx > m_run + kLazy)) {  // also every row's first unmasked tile (m_run = -inf)
+        const float m_new = fmaxf(m_run, mx);
+        // a row whose keys are all masked so far keeps m = -inf; guard the inf - inf
+        const float m_old = m_run == -INFINITY ? 0.f : m_run;
+        const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_old - m_ref);
+        m_run = m_new;
+        l_run *= alpha;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
+      const float m_use = m_run == -INFINITY ? 0.f : m_run;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // raw v_exp_f32: the argument is <= kLazy, and a result below 2^-126 may flush to zero
+          const float p = __builtin_amdgcn_exp2f(s[kt][r] - m_use);
+          s[kt][r] = p;
+          psum += p;
+        }
+      l_run += psum;
       // ---- O^T[d][q] += V^T . P^T ; registers 8s..8s+7 of a score tile are the B fragment of
       //      16-key step s, element j <-> key 16s + 8(j>>2) + 4half + (j&3) ----
 #pragma unroll
