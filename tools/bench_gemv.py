@@ -34,9 +34,6 @@ def main():
     st = kx.Stream()
     rng = np.random.default_rng(0)
     print(kx.device_name())
-    if os.environ.get("KX_DBG"):
-        import ctypes
-        ctypes.CDLL(os.path.join(ROOT, "llm-inference-engine_amd", "lib", "libkx_hip.so")).kx_debug_set(int(os.environ["KX_DBG"]))
     for name in which:
         for K, M in SHAPES[name]:
             per = K * M + 4 * K * M // GS
