@@ -259,7 +259,7 @@ def main():
         }
         if not args.no_prefill_kernels:
             line["prefill_kernels"] = prefill_kernels(kx, shape, world)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.model, bpt)
         print(json.dumps(line), flush=True)
     if dist is not None:
