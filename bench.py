@@ -196,7 +196,16 @@ def main():
     prefill_s = time.perf_counter() - t0
 
     use_graph = not args.no_graph
-    model.decode(max(args.warmup, 2), use_graph=use_graph)  # untimed; also captures the graph
+    try:
+        model.decode(max(args.warmup, 2), use_graph=use_graph)  # untimed; also captures the graph
+    except kx.KxError as e:
+        if not use_graph:
+            raise
+        # e.g. a collective that refuses stream capture: report eager numbers rather than none
+        print(f"[bench] graph replay unavailable ({e}); falling back to eager launches",
+              file=sys.stderr, flush=True)
+        use_graph = False
+        model.decode(max(args.warmup, 2), use_graph=False)
     fence()
     t0 = time.perf_counter()
     model.decode(args.steps, use_graph=use_graph)
