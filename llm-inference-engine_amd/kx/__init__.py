@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libkx_hip.so")
+LIB_PATH = os.environ.get("KX_HIP_LIB") or os.path.join(os.path.dirname(_PKG), "lib", "libkx_hip.so")
 
 ROPE_INTERLEAVED = 0
 ROPE_HALF_SPLIT = 1

@@ -382,7 +382,7 @@ def test_gemm_w8_vs_oracle(T, K, M):
     assert np.sqrt((err ** 2).mean()) <= 1e-4 * np.sqrt((absum ** 2).mean())
 
 
-@pytest.mark.parametrize("T,K,M", [(256, 128, 128), (300, 200, 256), (517, 384, 1024)])
+@pytest.mark.parametrize("T,K,M", [(256, 128, 128), (300, 200, 256), (517, 384, 1024), (1100, 200, 128)])
 def test_gemm_w8_two_pass_vs_oracle(T, K, M):
     # long-prompt form: X and scale*w each rounded once to fp16 (2^-11 relative, per element)
     rng = np.random.default_rng(T + K + M)
