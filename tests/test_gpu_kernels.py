@@ -271,6 +271,44 @@ def test_mha_decode_ignores_rows_past_pos():
     assert np.array_equal(a, b)
 
 
+def test_attention_and_gemm_preconditions():
+    # every entry checks its operands on the host and returns a code; nothing is launched
+    L = kx.lib()
+    b = kx.Buf(1 << 16)
+    ws = kx.Buf.zeros(1 << 16, np.uint8)
+    EINVAL, EUNSUP, EWS = -1, -2, -3
+    # position outside the cache, heads not divisible by kv_mul, kv_dim inconsistent
+    assert L.kx_mha_decode_f32(b.ptr, b.ptr, b.ptr, b.ptr, 16, 4, 2, 32, 64, 16, 0, ws.ptr, 1 << 16, None) == EINVAL
+    assert L.kx_mha_decode_f32(b.ptr, b.ptr, b.ptr, b.ptr, 3, 5, 2, 32, 64, 16, 0, ws.ptr, 1 << 16, None) == EINVAL
+    assert L.kx_mha_decode_f32(b.ptr, b.ptr, b.ptr, b.ptr, 3, 4, 2, 32, 96, 16, 0, ws.ptr, 1 << 16, None) == EINVAL
+    assert L.kx_mha_decode_f32(None, b.ptr, b.ptr, b.ptr, 3, 4, 2, 32, 64, 16, 0, ws.ptr, 1 << 16, None) == EINVAL
+    # a head size the tiled kernel is not built for needs the [head][seq_len] score scratch
+    assert L.kx_mha_decode_f32(b.ptr, b.ptr, b.ptr, b.ptr, 3, 4, 2, 8, 16, 16, 0, None, 0, None) == EWS
+    # ... and cannot read the position from device memory
+    assert L.kx_mha_decode_dpos_f32(b.ptr, b.ptr, b.ptr, b.ptr, b.ptr, 15, 4, 2, 8, 16, 16, 0, ws.ptr,
+                                    1 << 16, None) == EUNSUP
+    assert L.kx_mha_decode_dpos_f32(b.ptr, b.ptr, b.ptr, b.ptr, None, 15, 4, 2, 32, 64, 16, 0, ws.ptr,
+                                    1 << 16, None) == EINVAL
+    # flash attention: more query rows than positions, bad head grouping
+    scale = float(1 / np.sqrt(32))
+    assert L.kx_flash_attention_f32(b.ptr, b.ptr, b.ptr, b.ptr, 8, 4, 2, 32, 16, 3, 0, scale, 1, ws.ptr,
+                                    1 << 16, None) == EINVAL
+    assert L.kx_flash_attention_f32(b.ptr, b.ptr, b.ptr, b.ptr, 2, 4, 3, 32, 16, 3, 0, scale, 1, ws.ptr,
+                                    1 << 16, None) == EINVAL
+    # single rows go through the decode kernel, which takes the default scale only
+    assert L.kx_flash_attention_f32(b.ptr, b.ptr, b.ptr, b.ptr, 1, 4, 2, 32, 16, 3, 0, 0.5, 1, ws.ptr,
+                                    1 << 16, None) == EUNSUP
+    # GEMM: a routed column range without its destination, split points out of order
+    assert L.kx_gemm_w8_f32_ex(b.ptr, 64, b.ptr, b.ptr, 64, b.ptr, 64, b.ptr, 64, None, 0, 8, 16, None, 0,
+                               4, 64, 32, None) == EINVAL
+    assert L.kx_gemm_w8_f32_ex(b.ptr, 64, b.ptr, b.ptr, 64, b.ptr, 64, b.ptr, 64, b.ptr, 64, 16, 8, None,
+                               0, 4, 64, 32, None) == EINVAL
+    assert L.kx_gemm_w8_f32(None, b.ptr, b.ptr, 64, b.ptr, 4, 64, 32, None) == EINVAL
+    assert L.kx_gemm_w8_workspace_bytes(0, 64, 64) == 0
+    assert L.kx_flash_attention_workspace_bytes(-1, 2, 64) == 0
+    kx.sync()
+
+
 # ------------------------------- support kernels -------------------------------------------------
 def _run(fn, *args):
     kx.check(fn(*args))
