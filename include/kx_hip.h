@@ -159,6 +159,20 @@ int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float*
                       int64_t ld2, int32_t k0, int32_t k1, const float* residual, int64_t ldr,
                       int32_t T, int32_t M, int32_t K, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* The long-prompt pipeline keeps activations in fp16 between its kernels (new capability; the
+ * reference has no prompt batching).  X16 is fp16 [T][M], dense.  mode KX_GEMM_ROUTE_F32: fp32
+ * outputs with the routing / residual contract of kx_gemm_w8_f32_ex.  mode KX_GEMM_SWIGLU_F16: w
+ * is [gate rows | up rows] (K/2 each, K % 64 == 0) and h16 receives silu(gate)*up as fp16
+ * [T][K/2] (swiglu_kernel_cu, cuda/swiglu_kernel.cu:4-22, fused into the epilogue).  The
+ * workspace (kx_gemm_w8_f16act_workspace_bytes, 256-byte aligned) holds the fp16 weights. */
+#define KX_GEMM_ROUTE_F32 0
+#define KX_GEMM_SWIGLU_F16 1
+size_t kx_gemm_w8_f16act_workspace_bytes(int32_t M, int32_t K);
+int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales, int32_t group_size,
+                         int32_t mode, void* h16, float* y0, int64_t ld0, float* y1, int64_t ld1,
+                         float* y2, int64_t ld2, int32_t k0, int32_t k1, const float* residual,
+                         int64_t ldr, int32_t T, int32_t M, int32_t K, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, int32_t K,
                 void* stream);
 
@@ -197,6 +211,13 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
  * 0..that position when causal, 0..pos otherwise; kv head = h / (head_num/kv_head_num).
  * Tq == 1 is kx_mha_decode_f32.  Tq > 1 runs the MFMA kernel (fp16 operands, fp32 softmax and
  * accumulation). */
+/* kx_flash_attention_f32 with the output rows written as fp16 [Tq][head_num][head_size]
+ * (Tq > 1 and head sizes 32/64/128 only). */
+int kx_flash_attention_f16out(const float* query, const float* key_cache, const float* value_cache,
+                              void* out16, int32_t Tq, int32_t head_num, int32_t kv_head_num,
+                              int32_t head_size, int32_t seq_len, int32_t pos, int32_t layer_idx,
+                              float softmax_scale, int32_t is_causal, void* workspace,
+                              size_t workspace_bytes, void* stream);
 /* Workspace for Tq > 1 that lets the kernel work from fp16 copies of the layer's K/V rows 0..pos
  * (made once per call).  The first 16 KiB are left untouched, so the decode workspace, grown to
  * this size, can serve both.  With a smaller workspace each workgroup converts the fp32 rows it
@@ -214,6 +235,9 @@ int kx_flash_attention_f32(const float* query, const float* key_cache, const flo
  * rows of `dim`. */
 int kx_rmsnorm_f32(const float* in, const float* weight, float* out, int32_t dim, int32_t rows,
                    float eps, void* stream);
+/* The same normalisation with fp16 output rows (input of kx_gemm_w8_f16act_ws). */
+int kx_rmsnorm_f16out(const float* in, const float* weight, void* out16, int32_t dim, int32_t rows,
+                      float eps, void* stream);
 /* sin_cos_calc (cuda/rope_kernel.cu:38-49,84-95,130-136) with theta at run time. */
 int kx_sin_cos_cache_f32(int32_t head_size, int32_t max_seq_len, float theta, float* sin_cache,
                          float* cos_cache, void* stream);

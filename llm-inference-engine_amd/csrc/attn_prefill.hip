@@ -79,6 +79,7 @@ struct FaArgs {
   int32_t hpb;      // query heads per workgroup (divides kv_mul)
   int32_t qsubs;    // 32-row sub-blocks per workgroup
   float scale;
+  _Float16* out16;       // when set, the output is written here as fp16 instead of to `out`
   const _Float16* k16;   // fp16 copies (see kv_to_f16_kernel), or null
   const _Float16* v16t;
   int32_t s_pad;
@@ -384,14 +385,20 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   l_run += lane_xor32(l_run);
   if (my_row < a.Tq) {
     const float inv = 1.0f / l_run;
-    float* op = a.out + ((size_t)my_row * a.H + head) * HS + 4 * half;
+    const size_t off = ((size_t)my_row * a.H + head) * HS + 4 * half;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
                    o[dt][4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(op + 32 * dt + 8 * g) = v;
+        if (a.out16) {
+          f16x4 h;
+          h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+          *reinterpret_cast<f16x4*>(a.out16 + off + 32 * dt + 8 * g) = h;
+        } else {
+          *reinterpret_cast<f32x4*>(a.out + off + 32 * dt + 8 * g) = v;
+        }
       }
   }
 }
@@ -441,14 +448,13 @@ extern "C" size_t kx_flash_attention_workspace_bytes(int32_t pos, int32_t kv_hea
   return kx::FA_WS_SKIP + 2 * (size_t)kv_head_num * s_pad * head_size * 2;
 }
 
-extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache,
-                                      const float* value_cache, float* out, int32_t Tq,
-                                      int32_t head_num, int32_t kv_head_num, int32_t head_size,
-                                      int32_t seq_len, int32_t pos, int32_t layer_idx,
-                                      float softmax_scale, int32_t is_causal, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+static int flash_attention_run(const float* query, const float* key_cache, const float* value_cache,
+                               float* out, _Float16* out16, int32_t Tq, int32_t head_num,
+                               int32_t kv_head_num, int32_t head_size, int32_t seq_len, int32_t pos,
+                               int32_t layer_idx, float softmax_scale, int32_t is_causal,
+                               void* workspace, size_t workspace_bytes, void* stream) {
   using namespace kx;
-  if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
+  if (!query || !key_cache || !value_cache || (!out && !out16)) return KX_EINVAL;
   if (Tq <= 0 || head_num <= 0 || kv_head_num <= 0 || head_num % kv_head_num) return KX_EINVAL;
   if (pos < 0 || pos >= seq_len || pos - (Tq - 1) < 0) return KX_EINVAL;
   const int kv_mul = head_num / kv_head_num;
@@ -457,6 +463,7 @@ extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache
   const bool tiled = (head_size == 32 || head_size == 64 || head_size == 128) &&
                      (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache |
                        (uintptr_t)out) % 16 == 0);
+  if (out16 && (Tq == 1 || !tiled || (uintptr_t)out16 % 8)) return KX_EUNSUPPORTED;
   if (Tq == 1 || !tiled) {
     // single rows (and head sizes the tiled kernel is not built for) go through the decode
     // kernel row by row; it takes the default scale only
@@ -481,6 +488,7 @@ extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache
   const size_t layer_off = (size_t)layer_idx * (size_t)seq_len * (size_t)kv_dim;
   FaArgs a{};
   a.q = query; a.kc = key_cache + layer_off; a.vc = value_cache + layer_off; a.out = out;
+  a.out16 = out16;
   a.Tq = Tq; a.H = head_num; a.kv_mul = kv_mul; a.kv_dim = kv_dim; a.pos = pos;
   a.causal = is_causal ? 1 : 0; a.hpb = hpb; a.qsubs = qsubs; a.scale = softmax_scale;
   const int qblocks = (Tq + 32 * qsubs - 1) / (32 * qsubs);
@@ -490,4 +498,28 @@ extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache
     case 64: return launch_prefill<64>(a, kv_head_num, threads, qblocks, workspace, workspace_bytes, s);
     default: return launch_prefill<128>(a, kv_head_num, threads, qblocks, workspace, workspace_bytes, s);
   }
+}
+
+extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache,
+                                      const float* value_cache, float* out, int32_t Tq,
+                                      int32_t head_num, int32_t kv_head_num, int32_t head_size,
+                                      int32_t seq_len, int32_t pos, int32_t layer_idx,
+                                      float softmax_scale, int32_t is_causal, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (!out) return KX_EINVAL;
+  return flash_attention_run(query, key_cache, value_cache, out, nullptr, Tq, head_num, kv_head_num,
+                             head_size, seq_len, pos, layer_idx, softmax_scale, is_causal, workspace,
+                             workspace_bytes, stream);
+}
+
+extern "C" int kx_flash_attention_f16out(const float* query, const float* key_cache,
+                                         const float* value_cache, void* out16, int32_t Tq,
+                                         int32_t head_num, int32_t kv_head_num, int32_t head_size,
+                                         int32_t seq_len, int32_t pos, int32_t layer_idx,
+                                         float softmax_scale, int32_t is_causal, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!out16) return KX_EINVAL;
+  return flash_attention_run(query, key_cache, value_cache, nullptr, static_cast<_Float16*>(out16),
+                             Tq, head_num, kv_head_num, head_size, seq_len, pos, layer_idx,
+                             softmax_scale, is_causal, workspace, workspace_bytes, stream);
 }

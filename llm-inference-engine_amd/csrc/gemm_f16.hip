@@ -28,6 +28,7 @@ struct GemmF16Args {
   const _Float16* W;   // [K][M]
   const float* colf;   // [K] power-of-two row factors
   const float* residual;
+  _Float16* h16;       // SwiGLU form: fp16 [T][K/2] output
   float* y0; float* y1; float* y2;
   int64_t ld0, ld1, ld2, ldr;
   int32_t k0, k1;
@@ -54,10 +55,18 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
                                                               const float* __restrict__ scales,
                                                               _Float16* __restrict__ w16,
                                                               float* __restrict__ colf, int M, int K,
-                                                              int gs_shift) {
+                                                              int gs_shift, int swiglu_half) {
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= K) return;
+  // SwiGLU form (W = [gate rows | up rows], swiglu_half rows each): blocks of 32 gate rows and
+  // the matching 32 up rows are stored next to each other, so that one wave of the GEMM holds
+  // gate and up of the same hidden units in the same lane and register
+  int q = p;
+  if (swiglu_half > 0) {
+    const int j = p < swiglu_half ? p : p - swiglu_half;
+    q = (j >> 5) * 64 + (p < swiglu_half ? 0 : 32) + (j & 31);
+  }
   const int groups = M >> gs_shift;
   const float* sp = scales + (size_t)p * groups;
   float mx = 0.f;
@@ -66,9 +75,9 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
   // smallest power of two >= the row's largest scaled weight (1 for an all-zero row)
   const float f = mx > 0.f ? exp2f(ceilf(log2f(mx))) : 1.0f;
   const float inv = 1.0f / f;
-  if (lane == 0) colf[p] = f;
+  if (lane == 0) colf[q] = f;
   const int8_t* wp = w + (size_t)p * M;
-  _Float16* op = w16 + (size_t)p * M;
+  _Float16* op = w16 + (size_t)q * M;
   for (int c = lane * 16; c < M; c += 1024) {
     const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + c));
     const float s = sp[c >> gs_shift] * inv;
@@ -95,7 +104,9 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
 // is kept at chunk position c ^ ((r >> 1) & 7) instead (applied to the SOURCE address when
 // filling and to the LDS address when reading), which spreads any 16 consecutive rows of one
 // fragment column over all 64 banks.
-template <int MI, int NI>
+// SWIGLU: W16 holds gate/up rows interleaved in blocks of 32 (see the dequant kernel); the
+// epilogue writes silu(gate) * up as fp16 (swiglu_kernel_cu, cuda/swiglu_kernel.cu:4-22).
+template <int MI, int NI, bool SWIGLU>
 __device__ __forceinline__ void gemm_f16_body(const GemmF16Args& a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using lds_ptr_t = __attribute__((address_space(3))) void*;
@@ -177,6 +188,28 @@ __device__ __forceinline__ void gemm_f16_body(const GemmF16Args& a) {
   }
 
   // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  if constexpr (SWIGLU) {
+    static_assert(NI % 2 == 0, "gate/up blocks come in pairs");
+    const int half_k = a.K / 2;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni += 2) {
+      const int n = n0 + wc * 32 * NI + ni * 32 + frow;  // gate row in the interleaved order
+      if (n >= a.K) continue;
+      const int j = (n >> 6) * 32 + frow;                // hidden unit
+      const float fg = a.colf[n], fu = a.colf[n + 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = t0 + wr * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (t < a.T) {
+            const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 1][r] * fu;
+            a.h16[(size_t)t * half_k + j] = (_Float16)(g * (1.0f / (1.0f + expf(-g))) * u);
+          }
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wc * 32 * NI + ni * 32 + frow;
@@ -208,8 +241,10 @@ __device__ __forceinline__ void gemm_f16_body(const GemmF16Args& a) {
 }
 
 // the second launch bound is the number of 256-thread workgroups per CU the registers must allow
-__global__ __launch_bounds__(256, 4) void gemm_f16_kernel_22(const GemmF16Args a) { gemm_f16_body<2, 2>(a); }
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2>(a); }
+__global__ __launch_bounds__(256, 4) void gemm_f16_kernel_22(const GemmF16Args a) { gemm_f16_body<2, 2, false>(a); }
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, false>(a); }
+__global__ __launch_bounds__(256, 4) void gemm_f16_swiglu_kernel_22(const GemmF16Args a) { gemm_f16_body<2, 2, true>(a); }
+__global__ __launch_bounds__(256, 2) void gemm_f16_swiglu_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, true>(a); }
 
 template <int MI, int NI, typename Kern>
 static int launch_gemm_f16(Kern kern, const GemmF16Args& a, hipStream_t s) {
@@ -230,6 +265,72 @@ extern "C" size_t kx_gemm_w8_workspace_bytes(int32_t T, int32_t M, int32_t K) {
   return kx::align256((size_t)T * M * 2) + kx::align256((size_t)K * M * 2) + kx::align256((size_t)K * 4);
 }
 
+extern "C" size_t kx_gemm_w8_f16act_workspace_bytes(int32_t M, int32_t K) {
+  if (M <= 0 || K <= 0) return 0;
+  return kx::align256((size_t)K * M * 2) + kx::align256((size_t)K * 4);
+}
+
+static bool gemm_f16_shape_ok(int32_t group_size, int32_t M, const void* w, const void* workspace) {
+  const bool pow2 = (group_size & (group_size - 1)) == 0;
+  return pow2 && group_size >= 16 && M % group_size == 0 && M % kx::GF_BK == 0 &&
+         ((uintptr_t)w % 16 == 0) && ((uintptr_t)workspace % 256 == 0);
+}
+
+// Dequantises W into the workspace and runs the fp16 GEMM on fp16 activations.
+static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* scales,
+                           int32_t group_size, int32_t mode, _Float16* h16, float* y0, int64_t ld0,
+                           float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
+                           const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
+                           char* ws, hipStream_t s) {
+  using namespace kx;
+  _Float16* w16 = reinterpret_cast<_Float16*>(ws);
+  float* colf = reinterpret_cast<float*>(ws + align256((size_t)K * M * 2));
+  int gs_shift = 0;
+  while ((1 << gs_shift) < group_size) ++gs_shift;
+  const bool swiglu = mode == KX_GEMM_SWIGLU_F16;
+  hipLaunchKernelGGL(w8_dequant_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, w, scales, w16, colf,
+                     M, K, gs_shift, swiglu ? K / 2 : 0);
+  KX_LAUNCH_CHECK();
+  GemmF16Args a{};
+  a.X = x16; a.W = w16; a.colf = colf; a.residual = residual; a.h16 = h16;
+  a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
+  a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
+  a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
+  // 256 x 128 tiles (fewer LDS bytes per MFMA, 2 workgroups per CU) measured ~4 % faster than
+  // 128 x 128 (4 per CU) once there are enough row tiles; 128 x 256 and 3 per CU were slower
+  if (swiglu)
+    return T >= 1024 ? launch_gemm_f16<4, 2>(gemm_f16_swiglu_kernel_42, a, s)
+                     : launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s);
+  return T >= 1024 ? launch_gemm_f16<4, 2>(gemm_f16_kernel_42, a, s)
+                   : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
+}
+
+extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales,
+                                    int32_t group_size, int32_t mode, void* h16, float* y0,
+                                    int64_t ld0, float* y1, int64_t ld1, float* y2, int64_t ld2,
+                                    int32_t k0, int32_t k1, const float* residual, int64_t ldr,
+                                    int32_t T, int32_t M, int32_t K, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!X16 || !w || !scales || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
+  if (!workspace || workspace_bytes < kx_gemm_w8_f16act_workspace_bytes(M, K)) return KX_EWORKSPACE;
+  if (!gemm_f16_shape_ok(group_size, M, w, workspace) || (uintptr_t)X16 % 16) return KX_EUNSUPPORTED;
+  if (mode == KX_GEMM_SWIGLU_F16) {
+    // gate rows [0, K/2), up rows [K/2, K); whole blocks of 32 hidden units
+    if (!h16 || K % 64 || residual) return KX_EINVAL;
+    k0 = k1 = K;
+  } else if (mode == KX_GEMM_ROUTE_F32) {
+    if (!y0) return KX_EINVAL;
+    if (!y1 && !y2) { k0 = K; k1 = K; }
+    if (k0 < 0 || k1 < k0 || k1 > K) return KX_EINVAL;
+    if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
+  } else {
+    return KX_EINVAL;
+  }
+  return gemm_f16act_run(static_cast<const _Float16*>(X16), w, scales, group_size, mode,
+                         static_cast<_Float16*>(h16), y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
+                         T, M, K, static_cast<char*>(workspace), (hipStream_t)stream);
+}
+
 extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float* scales,
                                  int32_t group_size, float* y0, int64_t ld0, float* y1,
                                  int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
@@ -237,11 +338,9 @@ extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, c
                                  int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
   using namespace kx;
   if (!X || !w || !scales || !y0 || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
-  const bool pow2 = (group_size & (group_size - 1)) == 0;
   const bool two_pass = workspace && workspace_bytes >= kx_gemm_w8_workspace_bytes(T, M, K) &&
-                        T >= 2 * GF_BM && pow2 && group_size >= 16 && M % group_size == 0 &&
-                        M % GF_BK == 0 && ldx % 4 == 0 && ((uintptr_t)X % 16 == 0) &&
-                        ((uintptr_t)w % 16 == 0) && ((uintptr_t)workspace % 256 == 0);
+                        T >= 2 * GF_BM && gemm_f16_shape_ok(group_size, M, w, workspace) &&
+                        ldx % 4 == 0 && ((uintptr_t)X % 16 == 0);
   if (!two_pass)  // short prompts: converting the whole matrix would cost more than it saves
     return kx_gemm_w8_f32_ex(X, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1,
                              residual, ldr, T, M, K, stream);
@@ -251,23 +350,9 @@ extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, c
   hipStream_t s = (hipStream_t)stream;
   char* ws = static_cast<char*>(workspace);
   _Float16* x16 = reinterpret_cast<_Float16*>(ws);
-  _Float16* w16 = reinterpret_cast<_Float16*>(ws + align256((size_t)T * M * 2));
-  float* colf = reinterpret_cast<float*>(ws + align256((size_t)T * M * 2) + align256((size_t)K * M * 2));
-  int gs_shift = 0;
-  while ((1 << gs_shift) < group_size) ++gs_shift;
   const int64_t n4 = (int64_t)T * (M / 4);
   hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(2048), dim3(256), 0, s, X, ldx, x16, M, n4);
   KX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(w8_dequant_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, w, scales, w16, colf,
-                     M, K, gs_shift);
-  KX_LAUNCH_CHECK();
-  GemmF16Args a{};
-  a.X = x16; a.W = w16; a.colf = colf; a.residual = residual;
-  a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
-  a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
-  a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
-  // 256 x 128 tiles (fewer LDS bytes per MFMA, 2 workgroups per CU) measured ~4 % faster than
-  // 128 x 128 (4 per CU) once there are enough row tiles; 128 x 256 and 3 per CU were slower
-  if (T >= 1024) return launch_gemm_f16<4, 2>(gemm_f16_kernel_42, a, s);
-  return launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
+  return gemm_f16act_run(x16, w, scales, group_size, KX_GEMM_ROUTE_F32, nullptr, y0, ld0, y1, ld1, y2,
+                         ld2, k0, k1, residual, ldr, T, M, K, ws + align256((size_t)T * M * 2), s);
 }

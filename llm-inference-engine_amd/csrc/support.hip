@@ -17,6 +17,29 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// The same normalisation with the result rounded to fp16 (activations of the prefill GEMMs).
+__global__ void rmsnorm_f16out_kernel(const float* __restrict__ in, const float* __restrict__ weight,
+                                      _Float16* __restrict__ out, int dim, float eps) {
+  __shared__ float red[16];
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(in + (size_t)blockIdx.x * dim);
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(weight);
+  f16x4* o4 = reinterpret_cast<f16x4*>(out + (size_t)blockIdx.x * dim);
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
+    const f32x4 v = x4[i];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = block_sum(ss, red);
+  const float rs = 1.0f / sqrtf(ss / (float)dim + eps);
+  for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
+    const f32x4 v = x4[i], w = w4[i];
+    f16x4 h;
+    h[0] = (_Float16)(w.x * (rs * v.x)); h[1] = (_Float16)(w.y * (rs * v.y));
+    h[2] = (_Float16)(w.z * (rs * v.z)); h[3] = (_Float16)(w.w * (rs * v.w));
+    o4[i] = h;
+  }
+}
+
 // row_rmsnorm_f32 (kuiper/source/op/kernels/cuda/rmsnorm_kernel.cu:62-108):
 // out = weight * (x * rsqrt(mean(x^2) + eps)); one workgroup per row.
 __global__ void rmsnorm_kernel(const float* __restrict__ in, const float* __restrict__ weight,
@@ -312,6 +335,17 @@ extern "C" int kx_rmsnorm_f32(const float* in, const float* weight, float* out, 
   const int threads = dim >= 4096 ? 512 : 256;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(threads), 0, (hipStream_t)stream, in, weight,
                      out, dim, eps);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_rmsnorm_f16out(const float* in, const float* weight, void* out16, int32_t dim,
+                                 int32_t rows, float eps, void* stream) {
+  if (!in || !weight || !out16 || dim <= 0 || rows <= 0) return KX_EINVAL;
+  if (dim % 4 || ((uintptr_t)in | (uintptr_t)weight) % 16 || (uintptr_t)out16 % 8) return KX_EINVAL;
+  const int threads = dim >= 4096 ? 512 : 256;
+  hipLaunchKernelGGL(rmsnorm_f16out_kernel, dim3(rows), dim3(threads), 0, (hipStream_t)stream, in,
+                     weight, static_cast<_Float16*>(out16), dim, eps);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

@@ -781,15 +781,46 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   float* kbase = static_cast<float*>(kv_->get_raw_buffer_k());
   float* vbase = static_cast<float*>(kv_->get_raw_buffer_v());
   const float* res = c.plan.carries_residual ? X : nullptr;
+  // shapes the fp16 kernels are built for (LDS-DMA K-steps of 64, 32-unit SwiGLU blocks)
+  const bool f16_ok = (gs & (gs - 1)) == 0 && gs >= 16 && dim % 64 == 0 && ql % 64 == 0 &&
+                      hl % 64 == 0 && dim % gs == 0 && ql % gs == 0 && hl % gs == 0 &&
+                      (c.head_size == 32 || c.head_size == 64 || c.head_size == 128);
   int32_t rows = 0;
   for (int32_t p0 = pos0; p0 < pos0 + n; p0 += rows) {
     rows = pos0 + n - p0 < chunk ? pos0 + n - p0 : chunk;
     KX_RET(kx_embedding_f32(history_dev_ + p0, rows, emb_, dim, c.vocab_size, X, st));
+    const bool f16_chunk = f16_ok && rows >= 256;
     for (int32_t l = 0; l < c.layer_num; ++l) {
       const LayerWeights& lw = layers_[l];
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
       float* krow = static_cast<float*>(k_ptr) + (size_t)p0 * kl;
       float* vrow = static_cast<float*>(v_ptr) + (size_t)p0 * kl;
+      if (f16_chunk) {
+        // long chunks keep the GEMM inputs in fp16: the norm and the attention kernel write fp16,
+        // SwiGLU runs in the epilogue of the W1|W3 GEMM; XN / ATT / HH are reused as fp16 rows
+        KX_RET(kx_rmsnorm_f16out(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
+        KX_RET(kx_gemm_w8_f16act_ws(XN, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs,
+                                    KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
+                                    nullptr, 0, rows, dim, lw.qkv.rows, gws, gemm_ws, st));
+        KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
+        KX_RET(kx_flash_attention_f16out(Q, kbase, vbase, ATT, rows, c.head_local, c.kv_head_local,
+                                         c.head_size, c.seq_len, p0 + rows - 1, l,
+                                         1.0f / std::sqrt((float)c.head_size), 1, hip_->attn_workspace,
+                                         hip_->attn_workspace_bytes, st));
+        KX_RET(kx_gemm_w8_f16act_ws(ATT, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs,
+                                    KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim,
+                                    res, dim, rows, ql, dim, gws, gemm_ws, st));
+        ST_RET(all_reduce(X, (size_t)rows * dim));
+        KX_RET(kx_rmsnorm_f16out(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
+        KX_RET(kx_gemm_w8_f16act_ws(XN, static_cast<const int8_t*>(lw.w13.w), lw.w13.s, gs,
+                                    KX_GEMM_SWIGLU_F16, HH, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0,
+                                    nullptr, 0, rows, dim, 2 * hl, gws, gemm_ws, st));
+        KX_RET(kx_gemm_w8_f16act_ws(HH, static_cast<const int8_t*>(lw.w2.w), lw.w2.s, gs,
+                                    KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim,
+                                    res, dim, rows, hl, dim, gws, gemm_ws, st));
+        ST_RET(all_reduce(X, (size_t)rows * dim));
+        continue;
+      }
       KX_RET(kx_rmsnorm_f32(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
       KX_RET(kx_gemm_w8_f32_ws(XN, dim, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs, Q, ql,
                                krow, kl, vrow, kl, ql, ql + kl, nullptr, 0, rows, dim,

@@ -64,6 +64,13 @@ SIGNATURES = {
     "kx_gemm_w8_f32_ws": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
                                     C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp, _sz,
                                     _vp]),
+    "kx_gemm_w8_f16act_workspace_bytes": (_sz, [_i32, _i32]),
+    "kx_gemm_w8_f16act_ws": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int64, _vp, C.c_int64,
+                                       _vp, C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32,
+                                       _vp, _sz, _vp]),
+    "kx_rmsnorm_f16out": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
+    "kx_flash_attention_f16out": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                            _i32, _f, _i32, _vp, _sz, _vp]),
     "kx_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
     "kx_flash_attention_workspace_bytes": (_sz, [_i32, _i32, _i32]),
@@ -282,7 +289,7 @@ def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspa
 
 
 def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx, softmax_scale=None,
-                    is_causal=True, f16_copies=True):
+                    is_causal=True, f16_copies=True, f16_out=False):
     L, S, kv_dim = kc.shape
     q = np.ascontiguousarray(q, np.float32).reshape(-1, head_num, head_size)
     Tq = q.shape[0]
@@ -297,11 +304,48 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
     else:
         wsb = min(wsb, lib().kx_flash_attention_workspace_bytes(pos, kv_head_num, head_size) - 1)
     ws = Buf.zeros(wsb, np.uint8)
+    if f16_out:
+        out16 = Buf.zeros(q.size, np.float16)
+        check(lib().kx_flash_attention_f16out(dq.ptr, dk.ptr, dv.ptr, out16.ptr, Tq, head_num,
+                                              kv_head_num, head_size, S, pos, layer_idx, softmax_scale,
+                                              1 if is_causal else 0, ws.ptr, wsb, None),
+              "kx_flash_attention_f16out")
+        return out16.numpy(np.float16, q.shape)
     check(lib().kx_flash_attention_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, Tq, head_num, kv_head_num,
                                        head_size, S, pos, layer_idx, softmax_scale,
                                        1 if is_causal else 0, ws.ptr, wsb, None),
           "kx_flash_attention_f32")
     return out.numpy(np.float32, q.shape)
+
+
+def gemm_w8_f16act(X16, w, s, group_size=64, swiglu=False):
+    """fp16 activations [T][M]; fp32 [T][K] out, or fp16 silu(gate)*up [T][K/2] with swiglu."""
+    K, M = w.shape
+    T = X16.shape[0]
+    dx, dw, ds = Buf.from_numpy(X16.astype(np.float16)), Buf.from_numpy(w.astype(np.int8)), \
+        Buf.from_numpy(s.astype(np.float32))
+    wsb = lib().kx_gemm_w8_f16act_workspace_bytes(M, K)
+    ws = Buf(wsb)
+    if swiglu:
+        h = Buf.zeros((T, K // 2), np.float16)
+        check(lib().kx_gemm_w8_f16act_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 1, h.ptr, None, 0, None,
+                                         0, None, 0, 0, 0, None, 0, T, M, K, ws.ptr, wsb, None),
+              "kx_gemm_w8_f16act_ws")
+        return h.numpy(np.float16, (T, K // 2))
+    dy = Buf.zeros((T, K))
+    check(lib().kx_gemm_w8_f16act_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 0, None, dy.ptr, K, None, 0,
+                                     None, 0, K, K, None, 0, T, M, K, ws.ptr, wsb, None),
+          "kx_gemm_w8_f16act_ws")
+    return dy.numpy(np.float32, (T, K))
+
+
+def rmsnorm_f16out(x, weight, eps=1e-5):
+    x = np.ascontiguousarray(x, np.float32)
+    rows, dim = x.shape
+    dx, dw = Buf.from_numpy(x), Buf.from_numpy(weight.astype(np.float32))
+    out = Buf.zeros((rows, dim), np.float16)
+    check(lib().kx_rmsnorm_f16out(dx.ptr, dw.ptr, out.ptr, dim, rows, eps, None), "kx_rmsnorm_f16out")
+    return out.numpy(np.float16, (rows, dim))
 
 
 def gemm_w8(X, w, s, group_size=64, two_pass=False):

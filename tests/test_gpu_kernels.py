@@ -441,6 +441,62 @@ def test_gemm_w8_two_pass_vs_oracle(T, K, M):
     assert np.all(got[:, 3] == 0)
 
 
+@pytest.mark.parametrize("T,K,M", [(256, 256, 256), (300, 448, 128), (1100, 512, 192)])
+def test_gemm_w8_f16_activations_and_fused_swiglu(T, K, M):
+    # fp16 rows in; fp32 rows out, or silu(gate)*up in fp16 from the [gate | up] matrix
+    rng = np.random.default_rng(T * 3 + K)
+    _, w, s = rand_w8(rng, K, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    X = X16.astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    absum = np.abs(X.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(K, M) *
+                                             np.abs(w.astype(np.float64))).T
+    tol = 2.0 ** -11 * absum + 1e-7 * np.abs(want).max()   # only scale*w is rounded here
+    got = kx.gemm_w8_f16act(X16, w, s, GS)
+    assert np.all(np.abs(got - want) <= tol)
+    h = kx.gemm_w8_f16act(X16, w, s, GS, swiglu=True).astype(np.float64)
+    g, u = want[:, :K // 2].astype(np.float64), want[:, K // 2:].astype(np.float64)
+    ref = g / (1.0 + np.exp(-g)) * u
+    tg, tu = tol[:, :K // 2], tol[:, K // 2:]
+    # d silu/dg is within [-0.1, 1.1]; plus the fp16 rounding of the result
+    bound = 1.1 * tg * np.abs(u) + tu * np.abs(g) + tg * tu + 2.0 ** -10 * np.abs(ref) + 1e-6
+    assert h.shape == (T, K // 2)
+    assert np.all(np.abs(h - ref) <= bound)
+
+
+def test_gemm_w8_f16_activations_preconditions():
+    L = kx.lib()
+    T, K, M = 256, 128, 128
+    x, w, s = kx.Buf.zeros((T, M), np.float16), kx.Buf.zeros((K, M), np.int8), kx.Buf.zeros(K * M // GS)
+    y, h = kx.Buf.zeros((T, K)), kx.Buf.zeros((T, K // 2), np.float16)
+    wsb = L.kx_gemm_w8_f16act_workspace_bytes(M, K)
+    assert wsb >= 2 * K * M + 4 * K
+    ws = kx.Buf(wsb)
+    call = lambda mode, hp, yp, k, wb, res=None: L.kx_gemm_w8_f16act_ws(
+        x.ptr, w.ptr, s.ptr, GS, mode, hp, yp, K, None, 0, None, 0, K, K, res, 0, T, M, k, ws.ptr, wb,
+        None)
+    assert call(0, None, y.ptr, K, wsb) == 0
+    assert call(1, h.ptr, None, K, wsb) == 0
+    assert call(0, None, None, K, wsb) == -1          # no fp32 output
+    assert call(1, None, y.ptr, K, wsb) == -1         # no fp16 output
+    assert call(1, h.ptr, None, 96, wsb) == -1        # not whole 32-unit blocks
+    assert call(1, h.ptr, None, K, wsb, y.ptr) == -1  # no residual in the SwiGLU form
+    assert call(2, h.ptr, y.ptr, K, wsb) == -1
+    assert call(0, None, y.ptr, K, wsb - 1) == -3
+    kx.sync()
+
+
+def test_rmsnorm_f16out_vs_oracle():
+    rng = np.random.default_rng(5)
+    for rows, dim in ((3, 256), (260, 4096), (17, 896)):
+        x = rng.standard_normal((rows, dim)).astype(np.float32) * 3
+        g = rng.standard_normal(dim).astype(np.float32)
+        want = np.stack([kxo.rmsnorm(r, g, 1e-5) for r in x])
+        got = kx.rmsnorm_f16out(x, g, 1e-5)
+        assert got.dtype == np.float16
+        np.testing.assert_allclose(got.astype(np.float32), want, rtol=2.0 ** -10, atol=1e-6)
+
+
 def test_gemm_w8_two_pass_routing_residual_and_fallback():
     rng = np.random.default_rng(31)
     T, dim, kvd, S = 260, 256, 128, 300
@@ -550,6 +606,10 @@ def test_flash_attention_vs_oracle(H, KVH, hs, S, pos, Tq, causal):
                                  f16_copies=f16_copies)
         np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
         assert np.sqrt(((got - want) ** 2).mean()) <= 4e-4
+    # fp16 output rows: the same numbers rounded once more
+    got16 = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, layer, is_causal=causal, f16_out=True)
+    assert got16.dtype == np.float16
+    np.testing.assert_allclose(got16.astype(np.float32), got, rtol=2.0 ** -10, atol=1e-6)
 
 
 def test_flash_attention_nan_past_pos_is_never_read():

@@ -203,11 +203,16 @@ def test_synthetic_model_fused_and_layer_paths_vs_oracle(shape):
           rope_variant=1, rope_theta=1e6, rms_eps=1e-6), 150),
     (dict(dim=768, hidden_dim=2048, layer_num=1, head_num=12, kv_head_num=12, vocab_size=512,
           rope_variant=0, rope_theta=1e4, rms_eps=1e-5), 64),
+    # 256 rows and more per call: activations stay in fp16 between the kernels of a layer
+    (dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+          rope_variant=1, rope_theta=5e5, rms_eps=1e-5), 420),
+    (dict(dim=512, hidden_dim=1536, layer_num=1, head_num=4, kv_head_num=4, vocab_size=640,
+          rope_variant=0, rope_theta=1e4, rms_eps=1e-6), 257),
 ])
 def test_batched_prefill_vs_oracle_rows(shape, n):
     # The batched prompt pass must leave the KV rows and last-row logits that n single-token steps
     # leave (fp16 operand rounding: 4e-3 of each tensor's range), also when split into two calls.
-    seq_len = 192
+    seq_len = max(192, n + 12)
     rng = np.random.default_rng(3)
     toks = rng.integers(0, shape["vocab_size"], n).astype(np.int32)
     m = host.Model(seq_len=seq_len, group_size=GS, **shape)
