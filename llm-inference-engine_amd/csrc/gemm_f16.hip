@@ -16,6 +16,7 @@
 // Deviation from the fp32 formula: one fp16 rounding of X and one of (scale * w), each 2^-11
 // relative, independent per element.
 #include <math.h>
+#include <stdlib.h>
 
 #include "kx_common.hpp"
 
@@ -92,6 +93,66 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
     }
     *reinterpret_cast<f16x8*>(op + c) = lo;
     *reinterpret_cast<f16x8*>(op + c + 8) = hi;
+  }
+}
+
+// Epilogue of one wave: acc[mi][ni] is the 32 x 32 block at rows trow0 + 32 mi, columns ncol0 + 32 ni;
+// C layout of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// Multiplies the power-of-two row factor back in and either routes columns to up to three
+// destinations (+ residual on the first), or (SWIGLU) writes silu(gate) * up as fp16.
+template <int MI, int NI, bool SWIGLU>
+__device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f32x16 (&acc)[MI][NI],
+                                                  int trow0, int ncol0, int lane) {
+  const int frow = lane & 31;
+  if constexpr (SWIGLU) {
+    static_assert(NI % 2 == 0, "gate/up blocks come in pairs");
+    const int half_k = a.K / 2;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni += 2) {
+      const int n = ncol0 + ni * 32 + frow;  // gate row in the interleaved order
+      if (n >= a.K) continue;
+      const int j = (n >> 6) * 32 + frow;                // hidden unit
+      const float fg = a.colf[n], fu = a.colf[n + 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = trow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (t < a.T) {
+            const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 1][r] * fu;
+            a.h16[(size_t)t * half_k + j] = (_Float16)(g * (1.0f / (1.0f + expf(-g))) * u);
+          }
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = ncol0 + ni * 32 + frow;
+    if (n >= a.K) continue;
+    const float f = a.colf[n];
+    float* dst;
+    int64_t ld;
+    int col;
+    bool add_res = false;
+    if (n < a.k0) {
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+    } else if (n < a.k1) {
+      dst = a.y1; ld = a.ld1; col = n - a.k0;
+    } else {
+      dst = a.y2; ld = a.ld2; col = n - a.k1;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = trow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (t < a.T) {
+          float v = acc[mi][ni][r] * f;
+          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
+          dst[(size_t)t * ld + col] = v;
+        }
+      }
   }
 }
 
@@ -187,57 +248,7 @@ __device__ __forceinline__ void gemm_f16_body(const GemmF16Args& a) {
     __syncthreads();
   }
 
-  // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  if constexpr (SWIGLU) {
-    static_assert(NI % 2 == 0, "gate/up blocks come in pairs");
-    const int half_k = a.K / 2;
-#pragma unroll
-    for (int ni = 0; ni < NI; ni += 2) {
-      const int n = n0 + wc * 32 * NI + ni * 32 + frow;  // gate row in the interleaved order
-      if (n >= a.K) continue;
-      const int j = (n >> 6) * 32 + frow;                // hidden unit
-      const float fg = a.colf[n], fu = a.colf[n + 32];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = t0 + wr * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (t < a.T) {
-            const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 1][r] * fu;
-            a.h16[(size_t)t * half_k + j] = (_Float16)(g * (1.0f / (1.0f + expf(-g))) * u);
-          }
-        }
-    }
-    return;
-  }
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wc * 32 * NI + ni * 32 + frow;
-    if (n >= a.K) continue;
-    const float f = a.colf[n];
-    float* dst;
-    int64_t ld;
-    int col;
-    bool add_res = false;
-    if (n < a.k0) {
-      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
-    } else if (n < a.k1) {
-      dst = a.y1; ld = a.ld1; col = n - a.k0;
-    } else {
-      dst = a.y2; ld = a.ld2; col = n - a.k1;
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = t0 + wr * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (t < a.T) {
-          float v = acc[mi][ni][r] * f;
-          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
-          dst[(size_t)t * ld + col] = v;
-        }
-      }
-  }
+  gemm_f16_epilogue<MI, NI, SWIGLU>(a, acc, t0 + wr * 32 * MI, n0 + wc * 32 * NI, lane);
 }
 
 // the second launch bound is the number of 256-thread workgroups per CU the registers must allow
@@ -245,6 +256,199 @@ __global__ __launch_bounds__(256, 4) void gemm_f16_kernel_22(const GemmF16Args a
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, false>(a); }
 __global__ __launch_bounds__(256, 4) void gemm_f16_swiglu_kernel_22(const GemmF16Args a) { gemm_f16_body<2, 2, true>(a); }
 __global__ __launch_bounds__(256, 2) void gemm_f16_swiglu_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, true>(a); }
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 output tile, 512 threads = 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64,
+// K-tiles of 64, one workgroup per CU, the whole 128 KiB of two K-tile buffers in one LDS array.
+// Unlike the kernels above, the LDS-DMA loads stay in flight ACROSS barriers: a K-tile is brought
+// in as four 16 KiB pieces, one piece per phase, each issued six to three phases before its
+// first read, into the buffer region whose previous contents were last read three phases
+// earlier.  Pieces (rows of the operand tile; every wave reads 1/2 of one A piece pair and 1/4 of
+// one B piece pair):
+//   0  B rows with bit 5 clear  (column block ni = 0 of every wave)   read in phase 3 of the previous tile
+//   1  A rows with bit 6 clear  (row blocks mi = 0, 1)                read in phase 0
+//   2  B rows with bit 5 set    (ni = 1)                              read in phase 1
+//   3  A rows with bit 6 set    (mi = 2, 3)                           read in phase 2
+// Phase g = 4 t + p issues piece (g + 6) % 4 of tile (g + 6) / 4, then waits `vmcnt(8)`: every
+// wave has two loads per piece, so all but the newest four pieces have landed -- the piece issued
+// in phase g is complete, for the issuing wave, at the wait of phase g + 4, and readable by all
+// waves from phase g + 5 (after a barrier the issuing wave passed later).  A phase is
+//   [LDS fragment reads | issue | wait]  barrier  [8 MFMAs]  barrier
+// and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave's reads overlap the
+// other's MFMAs.  Each phase multiplies a (2 x 1 block) quadrant of the wave tile by the full
+// K-tile; the two B register sets swap roles every tile.  Tiles past the end re-load the last
+// K-tile into dead regions, which keeps the counts uniform.
+constexpr int GP_BUF = 65536, GP_BOFF = 32768;
+constexpr int kPipeCus = 256;
+constexpr int GP_GROUP_N = 4;
+using gp_lds_ptr_t = __attribute__((address_space(3))) void*;
+
+struct GemmPipeCtx {
+  const _Float16* src[4][2];  // per piece: this lane's source of its two fill instructions
+  int dst[4][2];              // and their (wave-uniform) byte offsets inside a buffer
+  int abase, bbase;           // byte offset of this lane's fragment row in the A / B region
+  int coff[4];                // swizzled 16-byte chunk offset per k-step of 16
+  int nt;
+};
+
+template <int PIECE, int BUFSEL>
+__device__ __forceinline__ void gp_issue(char* smem, const GemmPipeCtx& c, int tile) {
+  const int koff = min(tile, c.nt - 1) * GF_BK;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    __builtin_amdgcn_global_load_lds(c.src[PIECE][j] + koff,
+                                     (gp_lds_ptr_t)(smem + BUFSEL * GP_BUF + c.dst[PIECE][j]), 16, 0, 0);
+}
+
+template <int BUFSEL, int BLOCK>
+__device__ __forceinline__ void gp_read_a(const char* smem, const GemmPipeCtx& c, f16x8 (&f)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    f[ks] = *reinterpret_cast<const f16x8*>(smem + BUFSEL * GP_BUF + BLOCK * 4096 + c.abase + c.coff[ks]);
+}
+
+template <int BUFSEL, int BLOCK>
+__device__ __forceinline__ void gp_read_b(const char* smem, const GemmPipeCtx& c, f16x8 (&f)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    f[ks] = *reinterpret_cast<const f16x8*>(smem + BUFSEL * GP_BUF + BLOCK * 4096 + c.bbase + c.coff[ks]);
+}
+
+// One phase: issue a piece, wait until all but the newest four pieces have landed, barrier, the
+// quadrant's 8 MFMAs (ACC rows MI0, MI0 + 1 x column block NI_), barrier.  The priority pair keeps
+// the compiler from moving MFMAs across the barriers in among the loads.
+#define GP_PHASE(PIECE, BUFSEL, TILE, MI0, NI_, BREG)                                                   \
+  gp_issue<PIECE, BUFSEL>(smem, c, TILE);                                                               \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
+    acc[MI0][NI_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], BREG[ks], acc[MI0][NI_], 0, 0, 0); \
+    acc[MI0 + 1][NI_] =                                                                                 \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], BREG[ks], acc[MI0 + 1][NI_], 0, 0, 0);        \
+  }                                                                                                     \
+  __builtin_amdgcn_s_setprio(0);                                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  __builtin_amdgcn_sched_barrier(0);
+
+// One K-tile (four phases).  PAR = t & 1 selects the buffer; bq0 holds column block 0 of this tile
+// on entry, bq1 receives column block 1 in phase 1 and column block 0 of tile t + 1 in phase 3.
+template <int PAR>
+__device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t, f32x16 (&acc)[4][2],
+                                        f16x8 (&af)[2][4], f16x8 (&bq0)[4], f16x8 (&bq1)[4]) {
+  // phase 0: rows 0-63 of the wave tile x column block 0
+  gp_read_a<PAR, 0>(smem, c, af[0]);
+  gp_read_a<PAR, 1>(smem, c, af[1]);
+  GP_PHASE(2, PAR ^ 1, t + 1, 0, 0, bq0);
+  // phase 1: rows 0-63 x column block 1
+  gp_read_b<PAR, 1>(smem, c, bq1);
+  GP_PHASE(3, PAR ^ 1, t + 1, 0, 1, bq1);
+  // phase 2: rows 64-127 x column block 1
+  gp_read_a<PAR, 2>(smem, c, af[0]);
+  gp_read_a<PAR, 3>(smem, c, af[1]);
+  GP_PHASE(0, PAR, t + 2, 2, 1, bq1);
+  // phase 3: rows 64-127 x column block 0; column block 0 of the next tile replaces block 1
+  gp_read_b<PAR ^ 1, 0>(smem, c, bq1);
+  GP_PHASE(1, PAR, t + 2, 2, 0, bq0);
+}
+
+template <bool SWIGLU>
+__device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // workgroups that share an XCD (ids equal mod 8) take consecutive tiles, walking down the token
+  // dimension first: they share W column panels through that XCD's L2
+  const int tiles_m = (a.T + 255) / 256;
+  const int nwg = gridDim.x, q8 = nwg >> 3, r8n = nwg & 7, xcd = blockIdx.x & 7;
+  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
+  // inside that sequence, panels of GP_GROUP_N column tiles are walked column-first: the ~32
+  // workgroups an XCD runs at a time then cover about 8 x 4 tiles and share 12 operand panels
+  // instead of 18
+  const int tiles_n = (a.K + 255) / 256;
+  const int panel = wgid / (tiles_m * GP_GROUP_N), local = wgid - panel * (tiles_m * GP_GROUP_N);
+  const int gn = min(GP_GROUP_N, tiles_n - panel * GP_GROUP_N);
+  const int t0 = (local / gn) * 256, n0 = (panel * GP_GROUP_N + local % gn) * 256;
+
+  GemmPipeCtx c;
+  c.nt = a.M / GF_BK;
+  {
+    const int r8 = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gi = 2 * wave + j;
+#pragma unroll
+      for (int piece = 0; piece < 4; ++piece) {
+        const bool is_a = piece & 1;
+        const int row = is_a ? (gi >> 3) * 128 + (gi & 7) * 8 + (piece == 3 ? 64 : 0)
+                             : (gi >> 2) * 64 + (gi & 3) * 8 + (piece == 2 ? 32 : 0);
+        const int rl = row + r8;
+        const int chunk = (lane & 7) ^ ((rl >> 1) & 7);
+        // rows past the end re-read the last valid row; their outputs are never stored
+        c.src[piece][j] = is_a ? a.X + (size_t)min(t0 + rl, a.T - 1) * a.M + chunk * 8
+                               : a.W + (size_t)min(n0 + rl, a.K - 1) * a.M + chunk * 8;
+        c.dst[piece][j] = (is_a ? 0 : GP_BOFF) + row * 128;
+      }
+    }
+    const int frow = lane & 31, khalf = lane >> 5, key = (frow >> 1) & 7;
+    c.abase = (wr * 128 + frow) * 128;
+    c.bbase = GP_BOFF + (wc * 64 + frow) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) c.coff[ks] = ((ks * 2 + khalf) ^ key) << 4;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  f16x8 af[2][4], bx[4], by[4];
+
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
+  // prologue: phases -6 .. -2 issue five pieces, phase -1 reads column block 0 of tile 0
+  gp_issue<0, 0>(smem, c, 0);
+  gp_issue<1, 0>(smem, c, 0);
+  gp_issue<2, 0>(smem, c, 0);
+  gp_issue<3, 0>(smem, c, 0);
+  gp_issue<0, 1>(smem, c, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();
+  gp_read_b<0, 0>(smem, c, bx);
+  gp_issue<1, 1>(smem, c, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < c.nt; t += 2) {
+    gp_tile<0>(smem, c, t, acc, af, bx, by);
+    if (t + 1 < c.nt) gp_tile<1>(smem, c, t + 1, acc, af, by, bx);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads target this LDS
+  gemm_f16_epilogue<4, 2, SWIGLU>(a, acc, t0 + wr * 128, n0 + wc * 64, lane);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
+__global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true>(a); }
+
+template <typename Kern>
+static int launch_gemm_f16_pipe(Kern kern, const GemmF16Args& a, hipStream_t s) {
+  const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
+  KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 2 * GP_BUF, s, a);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
 
 template <int MI, int NI, typename Kern>
 static int launch_gemm_f16(Kern kern, const GemmF16Args& a, hipStream_t s) {
@@ -296,13 +500,26 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
   a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
   a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
-  // 256 x 128 tiles (fewer LDS bytes per MFMA, 2 workgroups per CU) measured ~4 % faster than
-  // 128 x 128 (4 per CU) once there are enough row tiles; 128 x 256 and 3 per CU were slower
+  // Kernel choice (KX_GEMM_F16_KERNEL = 1 / 2 / 3 forces one, for A/B runs and tests):
+  //   3  pipelined 256 x 256, one workgroup per CU: fastest once the tiles fill the CUs evenly
+  //   2  256 x 128, two per CU: ~4 % faster than 1 with >= 8 row tiles
+  //   1  128 x 128, four per CU
+  int choice = 0;
+  if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);
+  if (choice < 1 || choice > 3) {
+    const long tiles = (long)((T + 255) / 256) * ((K + 255) / 256);
+    const long rounds = (tiles + kPipeCus - 1) / kPipeCus;
+    const bool even = tiles * 10 >= rounds * kPipeCus * 7;  // the CUs are at least ~70 % busy over the rounds
+    choice = (T >= 1024 && M >= 512 && even) ? 3 : T >= 1024 ? 2 : 1;
+  }
+  if (choice == 3)
+    return swiglu ? launch_gemm_f16_pipe(gemm_f16_pipe_swiglu_kernel, a, s)
+                  : launch_gemm_f16_pipe(gemm_f16_pipe_kernel, a, s);
   if (swiglu)
-    return T >= 1024 ? launch_gemm_f16<4, 2>(gemm_f16_swiglu_kernel_42, a, s)
-                     : launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s);
-  return T >= 1024 ? launch_gemm_f16<4, 2>(gemm_f16_kernel_42, a, s)
-                   : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
+    return choice == 2 ? launch_gemm_f16<4, 2>(gemm_f16_swiglu_kernel_42, a, s)
+                       : launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s);
+  return choice == 2 ? launch_gemm_f16<4, 2>(gemm_f16_kernel_42, a, s)
+                     : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
 }
 
 extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales,

@@ -464,6 +464,21 @@ def test_gemm_w8_f16_activations_and_fused_swiglu(T, K, M):
     assert np.all(np.abs(h - ref) <= bound)
 
 
+@pytest.mark.parametrize("choice", ["1", "2", "3"])
+@pytest.mark.parametrize("T,K,M", [(1100, 600, 192), (520, 256, 64), (1024, 512, 1024)])
+def test_gemm_w8_f16_every_tile_kernel(monkeypatch, choice, T, K, M):
+    # 128 x 128, 256 x 128 and the pipelined 256 x 256 kernel on ragged tiles, 1 / 3 / 16 K-tiles
+    monkeypatch.setenv("KX_GEMM_F16_KERNEL", choice)
+    rng = np.random.default_rng(int(choice) * 7 + T)
+    _, w, s = rand_w8(rng, K, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    want = kxo.gemm_w8(X16.astype(np.float32), w, s, GS, threads=8)
+    absum = np.abs(X16.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(K, M) *
+                                               np.abs(w.astype(np.float64))).T
+    got = kx.gemm_w8_f16act(X16, w, s, GS)
+    assert np.all(np.abs(got - want) <= 2.0 ** -11 * absum + 1e-7 * np.abs(want).max())
+
+
 def test_gemm_w8_f16_activations_preconditions():
     L = kx.lib()
     T, K, M = 256, 128, 128
