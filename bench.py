@@ -84,12 +84,24 @@ def prefill_kernels(kx, shape, tp, T=4096):
                                      None, 0, T, M, K, gws.ptr, gwsb, st.ptr), "gemm_w8")
     gemm_us = kx.time_graph(st, gemm, replays=5)
     gemm_flops = 2.0 * T * K * M
+    # the form the prompt pass runs: fp16 rows in, silu(gate) * up in fp16 out
+    X16 = kx.Buf(T * M * 2)
+    H16 = kx.Buf(T * (K // 2) * 2)
+    kx.check(L.kx_rmsnorm_f16out(X.ptr, sc.ptr, X16.ptr, M, T, 1e-5, st.ptr), "rmsnorm_f16out")
+
+    def gemm_swiglu():  # weight dequantisation pass included
+        kx.check(L.kx_gemm_w8_f16act_ws(X16.ptr, w.ptr, sc.ptr, 64, 1, H16.ptr, None, 0, None, 0, None,
+                                        0, 0, 0, None, 0, T, M, K, gws.ptr, gwsb, st.ptr), "gemm_f16act")
+    fused_us = kx.time_graph(st, gemm_swiglu, replays=5) if K % 64 == 0 and T >= 256 else None
     return {
         "flash_attention": {"rows": T, "heads": H, "head_size": hs, "us": fa_us,
                             "tflops": fa_flops / fa_us / 1e6,
                             "mfma_util": fa_flops / fa_us / 1e6 / MFMA_F16_PEAK_TFLOPS},
         "gemm_w8": {"T": T, "K": K, "M": M, "us": gemm_us, "tflops": gemm_flops / gemm_us / 1e6,
                     "mfma_util": gemm_flops / gemm_us / 1e6 / MFMA_F16_PEAK_TFLOPS},
+        "gemm_w8_f16_swiglu": None if fused_us is None else {
+            "T": T, "K": K, "M": M, "us": fused_us, "tflops": gemm_flops / fused_us / 1e6,
+            "mfma_util": gemm_flops / fused_us / 1e6 / MFMA_F16_PEAK_TFLOPS},
         "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
     }
 

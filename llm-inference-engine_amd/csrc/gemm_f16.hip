@@ -156,6 +156,66 @@ __device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f3
   }
 }
 
+// The same epilogue for accumulators of v_mfma_f32_16x16x32_f16: acc[mi][ni] is the 16 x 16 block at
+// rows trow0 + 16 mi, columns ncol0 + 16 ni; col = lane & 15, row = 4 (lane >> 4) + r.  SWIGLU pairs
+// block ni (gate) with block ni + 2 (up): 32 gate columns are followed by their 32 up columns.
+template <int MI, int NI, bool SWIGLU>
+__device__ __forceinline__ void gemm_f16_epilogue16(const GemmF16Args& a, const f32x4 (&acc)[MI][NI],
+                                                    int trow0, int ncol0, int lane) {
+  const int fcol = lane & 15, frow4 = (lane >> 4) * 4;
+  if constexpr (SWIGLU) {
+    static_assert(NI % 4 == 0, "gate/up blocks come in groups of 2 + 2");
+    const int half_k = a.K / 2;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if ((ni & 2) != 0) continue;
+      const int n = ncol0 + ni * 16 + fcol;  // gate row in the interleaved order
+      if (n >= a.K) continue;
+      const int j = (n >> 6) * 32 + (n & 31);  // hidden unit
+      const float fg = a.colf[n], fu = a.colf[n + 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = trow0 + mi * 16 + frow4 + r;
+          if (t < a.T) {
+            const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 2][r] * fu;
+            a.h16[(size_t)t * half_k + j] = (_Float16)(g * (1.0f / (1.0f + expf(-g))) * u);
+          }
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = ncol0 + ni * 16 + fcol;
+    if (n >= a.K) continue;
+    const float f = a.colf[n];
+    float* dst;
+    int64_t ld;
+    int col;
+    bool add_res = false;
+    if (n < a.k0) {
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+    } else if (n < a.k1) {
+      dst = a.y1; ld = a.ld1; col = n - a.k0;
+    } else {
+      dst = a.y2; ld = a.ld2; col = n - a.k1;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = trow0 + mi * 16 + frow4 + r;
+        if (t < a.T) {
+          float v = acc[mi][ni][r] * f;
+          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
+          dst[(size_t)t * ld + col] = v;
+        }
+      }
+  }
+}
+
 // (64 MI) x (64 NI) output tile per 256-thread workgroup (4 waves as 2 x 2, each MI x NI
 // accumulator tiles of 32 x 32), K-step 64, operands brought in by the LDS-DMA path
 // (global_load_lds, 16 bytes per lane): no staging registers, no ds_write pass.  One buffer, two
@@ -258,26 +318,28 @@ __global__ __launch_bounds__(256, 4) void gemm_f16_swiglu_kernel_22(const GemmF1
 __global__ __launch_bounds__(256, 2) void gemm_f16_swiglu_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, true>(a); }
 
 // ---------------------------------------------------------------------------------------------
-// 256 x 256 output tile, 512 threads = 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64,
+// 256 x 256 output tile, 512 threads = 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64 as
+// 8 x 4 blocks of v_mfma_f32_16x16x32_f16 (on random data the chip holds a higher clock on this
+// shape than on 32x32x16: 975 -> 855 us for 4096 x 28672 x 4096 with nothing else changed),
 // K-tiles of 64, one workgroup per CU, the whole 128 KiB of two K-tile buffers in one LDS array.
 // Unlike the kernels above, the LDS-DMA loads stay in flight ACROSS barriers: a K-tile is brought
 // in as four 16 KiB pieces, one piece per phase, each issued six to three phases before its
 // first read, into the buffer region whose previous contents were last read three phases
 // earlier.  Pieces (rows of the operand tile; every wave reads 1/2 of one A piece pair and 1/4 of
 // one B piece pair):
-//   0  B rows with bit 5 clear  (column block ni = 0 of every wave)   read in phase 3 of the previous tile
-//   1  A rows with bit 6 clear  (row blocks mi = 0, 1)                read in phase 0
-//   2  B rows with bit 5 set    (ni = 1)                              read in phase 1
-//   3  A rows with bit 6 set    (mi = 2, 3)                           read in phase 2
+//   0  B rows with bit 5 clear  (columns 0-31 of every wave)    read in phase 3 of the previous tile
+//   1  A rows with bit 6 clear  (rows 0-63 of every wave)       read in phase 0
+//   2  B rows with bit 5 set    (columns 32-63)                 read in phase 1
+//   3  A rows with bit 6 set    (rows 64-127)                   read in phase 2
 // Phase g = 4 t + p issues piece (g + 6) % 4 of tile (g + 6) / 4, then waits `vmcnt(8)`: every
 // wave has two loads per piece, so all but the newest four pieces have landed -- the piece issued
 // in phase g is complete, for the issuing wave, at the wait of phase g + 4, and readable by all
 // waves from phase g + 5 (after a barrier the issuing wave passed later).  A phase is
-//   [LDS fragment reads | issue | wait]  barrier  [8 MFMAs]  barrier
+//   [LDS fragment reads | issue | wait]  barrier  [16 MFMAs]  barrier
 // and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave's reads overlap the
-// other's MFMAs.  Each phase multiplies a (2 x 1 block) quadrant of the wave tile by the full
-// K-tile; the two B register sets swap roles every tile.  Tiles past the end re-load the last
-// K-tile into dead regions, which keeps the counts uniform.
+// other's MFMAs.  Each phase multiplies a 64 x 32 quadrant of the wave tile by the full K-tile;
+// the two B register sets swap roles every tile.  Tiles past the end re-load the last K-tile
+// into dead regions, which keeps the counts uniform.
 constexpr int GP_BUF = 65536, GP_BOFF = 32768;
 constexpr int kPipeCus = 256;
 constexpr int GP_GROUP_N = 4;
@@ -287,7 +349,7 @@ struct GemmPipeCtx {
   const _Float16* src[4][2];  // per piece: this lane's source of its two fill instructions
   int dst[4][2];              // and their (wave-uniform) byte offsets inside a buffer
   int abase, bbase;           // byte offset of this lane's fragment row in the A / B region
-  int coff[4];                // swizzled 16-byte chunk offset per k-step of 16
+  int coff[2];                // swizzled 16-byte chunk offset per k-step of 32
   int nt;
 };
 
@@ -300,24 +362,21 @@ __device__ __forceinline__ void gp_issue(char* smem, const GemmPipeCtx& c, int t
                                      (gp_lds_ptr_t)(smem + BUFSEL * GP_BUF + c.dst[PIECE][j]), 16, 0, 0);
 }
 
-template <int BUFSEL, int BLOCK>
-__device__ __forceinline__ void gp_read_a(const char* smem, const GemmPipeCtx& c, f16x8 (&f)[4]) {
+// fragments of v_mfma_f32_16x16x32_f16: BLOCKS consecutive 16-row blocks x two k-steps of 32
+template <int BUFSEL, int BLOCK, int BLOCKS>
+__device__ __forceinline__ void gp_read16(const char* smem, int base, const int (&coff)[2],
+                                          f16x8 (&f)[BLOCKS][2]) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    f[ks] = *reinterpret_cast<const f16x8*>(smem + BUFSEL * GP_BUF + BLOCK * 4096 + c.abase + c.coff[ks]);
-}
-
-template <int BUFSEL, int BLOCK>
-__device__ __forceinline__ void gp_read_b(const char* smem, const GemmPipeCtx& c, f16x8 (&f)[4]) {
+  for (int b = 0; b < BLOCKS; ++b)
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    f[ks] = *reinterpret_cast<const f16x8*>(smem + BUFSEL * GP_BUF + BLOCK * 4096 + c.bbase + c.coff[ks]);
+    for (int kk = 0; kk < 2; ++kk)
+      f[b][kk] = *reinterpret_cast<const f16x8*>(smem + BUFSEL * GP_BUF + (BLOCK + b) * 2048 + base + coff[kk]);
 }
 
 // One phase: issue a piece, wait until all but the newest four pieces have landed, barrier, the
-// quadrant's 8 MFMAs (ACC rows MI0, MI0 + 1 x column block NI_), barrier.  The priority pair keeps
-// the compiler from moving MFMAs across the barriers in among the loads.
-#define GP_PHASE(PIECE, BUFSEL, TILE, MI0, NI_, BREG)                                                   \
+// quadrant's 16 MFMAs (row blocks MI0 .. MI0 + 3 x column blocks NI0, NI0 + 1), barrier.  The
+// priority pair keeps the compiler from moving MFMAs across the barriers in among the loads.
+#define GP_PHASE(PIECE, BUFSEL, TILE, MI0, NI0, BREG)                                                   \
   gp_issue<PIECE, BUFSEL>(smem, c, TILE);                                                               \
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -325,35 +384,33 @@ __device__ __forceinline__ void gp_read_b(const char* smem, const GemmPipeCtx& c
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                                        \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
-    acc[MI0][NI_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], BREG[ks], acc[MI0][NI_], 0, 0, 0); \
-    acc[MI0 + 1][NI_] =                                                                                 \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], BREG[ks], acc[MI0 + 1][NI_], 0, 0, 0);        \
-  }                                                                                                     \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                       \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
+        acc[MI0 + m][NI0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][kk], BREG[n][kk],          \
+                                                                       acc[MI0 + m][NI0 + n], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                        \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_barrier();                                                                         \
   __builtin_amdgcn_sched_barrier(0);
 
-// One K-tile (four phases).  PAR = t & 1 selects the buffer; bq0 holds column block 0 of this tile
-// on entry, bq1 receives column block 1 in phase 1 and column block 0 of tile t + 1 in phase 3.
+// One K-tile (four phases).  PAR = t & 1 selects the buffer; bq0 holds columns 0-31 of this tile on
+// entry, bq1 receives columns 32-63 in phase 1 and columns 0-31 of tile t + 1 in phase 3.
 template <int PAR>
-__device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t, f32x16 (&acc)[4][2],
-                                        f16x8 (&af)[2][4], f16x8 (&bq0)[4], f16x8 (&bq1)[4]) {
-  // phase 0: rows 0-63 of the wave tile x column block 0
-  gp_read_a<PAR, 0>(smem, c, af[0]);
-  gp_read_a<PAR, 1>(smem, c, af[1]);
+__device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t, f32x4 (&acc)[8][4],
+                                        f16x8 (&af)[4][2], f16x8 (&bq0)[2][2], f16x8 (&bq1)[2][2]) {
+  // phase 0: rows 0-63 of the wave tile x columns 0-31
+  gp_read16<PAR, 0, 4>(smem, c.abase, c.coff, af);
   GP_PHASE(2, PAR ^ 1, t + 1, 0, 0, bq0);
-  // phase 1: rows 0-63 x column block 1
-  gp_read_b<PAR, 1>(smem, c, bq1);
-  GP_PHASE(3, PAR ^ 1, t + 1, 0, 1, bq1);
-  // phase 2: rows 64-127 x column block 1
-  gp_read_a<PAR, 2>(smem, c, af[0]);
-  gp_read_a<PAR, 3>(smem, c, af[1]);
-  GP_PHASE(0, PAR, t + 2, 2, 1, bq1);
-  // phase 3: rows 64-127 x column block 0; column block 0 of the next tile replaces block 1
-  gp_read_b<PAR ^ 1, 0>(smem, c, bq1);
-  GP_PHASE(1, PAR, t + 2, 2, 0, bq0);
+  // phase 1: rows 0-63 x columns 32-63
+  gp_read16<PAR, 2, 2>(smem, c.bbase, c.coff, bq1);
+  GP_PHASE(3, PAR ^ 1, t + 1, 0, 2, bq1);
+  // phase 2: rows 64-127 x columns 32-63
+  gp_read16<PAR, 4, 4>(smem, c.abase, c.coff, af);
+  GP_PHASE(0, PAR, t + 2, 4, 2, bq1);
+  // phase 3: rows 64-127 x columns 0-31; columns 0-31 of the next tile replace columns 32-63
+  gp_read16<PAR ^ 1, 0, 2>(smem, c.bbase, c.coff, bq1);
+  GP_PHASE(1, PAR, t + 2, 4, 0, bq0);
 }
 
 template <bool SWIGLU>
@@ -395,21 +452,21 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
         c.dst[piece][j] = (is_a ? 0 : GP_BOFF) + row * 128;
       }
     }
-    const int frow = lane & 31, khalf = lane >> 5, key = (frow >> 1) & 7;
+    const int frow = lane & 15, kq = lane >> 4, key = (frow >> 1) & 7;
     c.abase = (wr * 128 + frow) * 128;
     c.bbase = GP_BOFF + (wc * 64 + frow) * 128;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) c.coff[ks] = ((ks * 2 + khalf) ^ key) << 4;
+    for (int kk = 0; kk < 2; ++kk) c.coff[kk] = ((kk * 4 + kq) ^ key) << 4;
   }
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-  f16x8 af[2][4], bx[4], by[4];
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+  f16x8 af[4][2], bx[2][2], by[2][2];
 
   if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
   // prologue: phases -6 .. -2 issue five pieces, phase -1 reads column block 0 of tile 0
@@ -421,7 +478,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_s_barrier();
-  gp_read_b<0, 0>(smem, c, bx);
+  gp_read16<0, 0, 2>(smem, c.bbase, c.coff, bx);
   gp_issue<1, 1>(smem, c, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -434,7 +491,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads target this LDS
-  gemm_f16_epilogue<4, 2, SWIGLU>(a, acc, t0 + wr * 128, n0 + wc * 64, lane);
+  gemm_f16_epilogue16<8, 4, SWIGLU>(a, acc, t0 + wr * 128, n0 + wc * 64, lane);
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
