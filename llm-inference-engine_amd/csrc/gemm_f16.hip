@@ -497,12 +497,17 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true>(a); }
 
-template <typename Kern>
-static int launch_gemm_f16_pipe(Kern kern, const GemmF16Args& a, hipStream_t s) {
+template <void (*KERN)(GemmF16Args)>
+static int launch_gemm_f16_pipe(const GemmF16Args& a, hipStream_t s) {
   const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
-  KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 2 * GP_BUF, s, a);
+  // 128 KiB of dynamic LDS needs the opt-in, once per kernel (one device per process)
+  static bool opted_in = false;  // one instance per kernel
+  if (!opted_in) {
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
+    opted_in = true;
+  }
+  hipLaunchKernelGGL(KERN, dim3(tiles_m * tiles_n), dim3(512), 2 * GP_BUF, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -562,7 +567,7 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   //   2  256 x 128, two per CU: ~4 % faster than 1 with >= 8 row tiles
   //   1  128 x 128, four per CU
   int choice = 0;
-  if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);
+  if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);  // a few ns; read per call so tests can switch
   if (choice < 1 || choice > 3) {
     const long tiles = (long)((T + 255) / 256) * ((K + 255) / 256);
     const long rounds = (tiles + kPipeCus - 1) / kPipeCus;
@@ -570,8 +575,8 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
     choice = (T >= 1024 && M >= 512 && even) ? 3 : T >= 1024 ? 2 : 1;
   }
   if (choice == 3)
-    return swiglu ? launch_gemm_f16_pipe(gemm_f16_pipe_swiglu_kernel, a, s)
-                  : launch_gemm_f16_pipe(gemm_f16_pipe_kernel, a, s);
+    return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, s)
+                  : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, s);
   if (swiglu)
     return choice == 2 ? launch_gemm_f16<4, 2>(gemm_f16_swiglu_kernel_42, a, s)
                        : launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s);

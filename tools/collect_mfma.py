@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         name = r["Kernel_Name"]
-        if "attn_prefill_kernel" in name or "gemm_f16_kernel" in name:
+        if "attn_prefill_kernel" in name or "gemm_f16_" in name:
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for name, c in acc.items():
