@@ -234,6 +234,22 @@ def main():
     fence()
     tok, pos = model.state()
 
+    # tensor-parallel runs: the all-reduce of one token (dim floats) and of a prompt block, on the
+    # token loop's own side-stream path.  Collective calls: every rank makes them.
+    comm = None
+    if world > 1:
+        try:
+            comm = {
+                "decode_allreduce_us": model.profile_allreduce(shape["dim"], 200) * 1e3,
+                "decode_allreduce_bytes": shape["dim"] * 4,
+                "prefill_allreduce_us": model.profile_allreduce(shape["dim"] * 4096, 10) * 1e3,
+                "prefill_allreduce_bytes": shape["dim"] * 4096 * 4,
+                "allreduces_per_token": 2 * shape["layer_num"],
+            }
+        except kx.KxError as e:  # evidence only: never lose the headline line over it
+            comm = {"error": str(e)}
+        fence()
+
     if rank == 0:
         bpt = model.linear_bytes_per_token() * world  # whole-model linear bytes per token
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
@@ -278,6 +294,12 @@ def main():
             "decode_hbm_gbps_end_to_end": (bpt + kv_bytes) * tok_s / 1e9 / world,
             "prefill_tok_per_s": args.context / prefill_s if args.context else None,
         }
+        if comm is not None:
+            if "decode_allreduce_us" in comm:
+                # share of a token's wall time the two reduces per layer account for if nothing overlaps
+                comm["allreduce_share_of_token"] = comm["decode_allreduce_us"] * 1e-3 * \
+                    comm["allreduces_per_token"] / (elapsed / args.steps * 1e3)
+            line["tensor_parallel_comm"] = comm
         if not args.no_prefill_kernels:
             line["prefill_kernels"] = prefill_kernels(kx, shape, world)
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed at N=1 only

@@ -50,6 +50,9 @@ int kxm_read_state(void* model, int32_t* token, int32_t* pos);
 int kxm_read_kv(void* model, int32_t layer, int32_t rows, float* k_host, float* v_host);
 int kxm_sync(void* model);
 int kxm_profile_gemv(void* model, int32_t steps, int64_t* launches, double* bytes, double* ms);
+/* Average milliseconds of one all-reduce of `count` floats on the token loop's own path (side
+ * stream between two events), `iters` calls back to back.  A collective: every rank calls it. */
+int kxm_profile_allreduce(void* model, uint64_t count, int32_t iters, double* ms);
 double kxm_linear_bytes_per_token(void* model);
 void* kxm_stream(void* model);
 

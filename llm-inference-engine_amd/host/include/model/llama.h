@@ -110,6 +110,9 @@ class LlamaModel {
   // Timing of the W8 GEMV launches of a decode step (replayed alone from a graph, `steps` times,
   // between two HIP events on the compute stream): launches, algorithmic bytes, milliseconds.
   base::Status profile_gemv(int32_t steps, int64_t* launches, double* bytes, double* ms);
+  // `iters` back-to-back all-reduces of `count` floats on the path the token loop uses (side stream
+  // between two events); ms = average per call.  A collective: every rank must call it.
+  base::Status profile_allreduce(size_t count, int32_t iters, double* ms);
 
   const TransformerConfig& config() const { return cfg_; }
   std::shared_ptr<kernel::CudaConfig> hip_config() const { return hip_; }

@@ -113,6 +113,9 @@ int kxm_sync(void* m) { return done(M(m)->sync()); }
 int kxm_profile_gemv(void* m, int32_t steps, int64_t* launches, double* bytes, double* ms) {
   return done(M(m)->profile_gemv(steps, launches, bytes, ms));
 }
+int kxm_profile_allreduce(void* m, uint64_t count, int32_t iters, double* ms) {
+  return done(M(m)->profile_allreduce((size_t)count, iters, ms));
+}
 double kxm_linear_bytes_per_token(void* m) { return M(m)->linear_weight_bytes_per_token(); }
 void* kxm_stream(void* m) { return M(m)->hip_config()->stream; }
 

@@ -887,6 +887,34 @@ base::Status LlamaModel::sync() const {
   return base::error::Success();
 }
 
+base::Status LlamaModel::profile_allreduce(size_t count, int32_t iters, double* ms) {
+  if (!ms || iters <= 0 || count == 0) return base::error::InvalidArgument("bad all-reduce profile request");
+  if (!comm_ready_ || loop_) return base::error::InvalidArgument("needs an RCCL communicator");
+  void* st = hip_->stream;
+  void* buf = nullptr;
+  KX_RET(kx_malloc(&buf, count * sizeof(float)));
+  KX_RET(kx_memset(buf, 0, count * sizeof(float), st));
+  void *e0 = nullptr, *e1 = nullptr;
+  KX_RET(kx_event_create(&e0));
+  KX_RET(kx_event_create(&e1));
+  base::Status s = base::error::Success();
+  for (int32_t i = 0; i < 3 && s; ++i) s = all_reduce(static_cast<float*>(buf), count);  // warm-up
+  if (s) {
+    KX_RET(kx_stream_sync(st));
+    KX_RET(kx_event_record(e0, st));
+    for (int32_t i = 0; i < iters && s; ++i) s = all_reduce(static_cast<float*>(buf), count);
+    KX_RET(kx_event_record(e1, st));
+    KX_RET(kx_event_sync(e1));
+    float t = 0.f;
+    KX_RET(kx_event_elapsed_ms(e0, e1, &t));
+    *ms = (double)t / iters;
+  }
+  kx_event_destroy(e0);
+  kx_event_destroy(e1);
+  kx_free(buf);
+  return s;
+}
+
 base::Status LlamaModel::profile_gemv(int32_t steps, int64_t* launches, double* bytes, double* ms) {
   // The W8 GEMV launches of ONE decode step, in model order and on the model's own buffers, are
   // captured alone into a graph (attention, embedding, sampling and collectives left out) and the

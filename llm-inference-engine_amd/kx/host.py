@@ -66,6 +66,7 @@ def hlib():
         L.kxm_sync.argtypes = [_vp]
         L.kxm_profile_gemv.argtypes = [_vp, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]
+        L.kxm_profile_allreduce.argtypes = [_vp, C.c_uint64, _i32, C.POINTER(C.c_double)]
         L.kxm_linear_bytes_per_token.restype = C.c_double
         L.kxm_linear_bytes_per_token.argtypes = [_vp]
         L.kxm_stream.restype = _vp
@@ -195,6 +196,12 @@ class Model:
         hcheck(hlib().kxm_profile_gemv(self.h, steps, C.byref(n), C.byref(b), C.byref(ms)),
                "kxm_profile_gemv")
         return n.value, b.value, ms.value
+
+    def profile_allreduce(self, count, iters):
+        ms = C.c_double()
+        hcheck(hlib().kxm_profile_allreduce(self.h, C.c_uint64(count), iters, C.byref(ms)),
+               "kxm_profile_allreduce")
+        return ms.value
 
     def linear_bytes_per_token(self):
         return hlib().kxm_linear_bytes_per_token(self.h)

@@ -273,6 +273,11 @@ def test_single_rank_communicator_runs_the_allreduce_path():
         last = m.prefill(toks)
         m.decode(12, use_graph=True)
         runs.append((last, m.history(len(toks) + 13)))
+        if with_comm:
+            assert m.profile_allreduce(512, 5) > 0.0    # ms per call on the side-stream path
+        else:
+            with pytest.raises(kx.KxError):
+                m.profile_allreduce(512, 5)             # no communicator
     np.testing.assert_array_equal(runs[0][0], runs[1][0])
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
 
