@@ -98,7 +98,7 @@ int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const float* scales
  * RMSNorm of x while it is staged (rmsnorm_kernel.cu:62-108 + llama3.cpp:637-646,755-759) and,
  * for mode KX_GEMV_QKV_ROPE, RoPE on the finished q/k rotation pairs (rope_kernel.cu) with k and
  * v written into their KV-cache row: y1/y2 point at the layer's [seq_len][kv_dim] block and are
- * advanced by pos*kv_pos_stride floats (model.cpp:237-245).  `pos_dev` (device int32) is read
+ * advanced by pos*kv_pos_stride elements (model.cpp:237-245).  `pos_dev` (device int32) is read
  * by the kernel when non-null, so a captured graph can be replayed as the position advances;
  * otherwise `pos` is used.  Unused pointer fields are NULL, unused ints 0. */
 enum { KX_GEMV_PLAIN = 0, KX_GEMV_GATE_UP = 1, KX_GEMV_QKV_ROPE = 2 };
@@ -125,6 +125,7 @@ typedef struct kx_gemv_w8_desc {
   int32_t rope_variant;  /* KX_ROPE_* */
   int32_t head_size;
   int32_t kv_pos_stride;
+  int32_t kv_f16;        /* non-zero: y1/y2 are fp16 cache blocks (16-bit KV cache); values are rounded once */
 } kx_gemv_w8_desc;
 int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* desc, void* stream);
 
@@ -203,6 +204,15 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
                            int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                            int32_t layer_index, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* 16-bit KV cache (not in the reference, whose cache is fp32: kv_cache_manager.cpp:6-40): the same
+ * single-token attention over caches of IEEE half rows, same [layer][seq_len][kv_dim] layout.
+ * K and V are widened to fp32 on load, so the only deviation from the fp32 cache is the one
+ * rounding of each stored K/V element (2^-11 relative).  pos_dev non-null: the position is read
+ * on the device and `pos` is the largest position the launch may see.  Head sizes 32/64/128. */
+int kx_mha_decode_kv16(const float* query, const void* key_cache16, const void* value_cache16,
+                       float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
+                       int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
+                       int32_t layer_index, void* workspace, size_t workspace_bytes, void* stream);
 
 /* kx_flash_attention_f32 replaces flash_attention_kernel_cu (cuda/flash_attention_kernel.cu:
  * 214-303) behind FlashAttentionKernel (kernels_interface.h:49-54).  Semantics (the reference
@@ -218,6 +228,14 @@ int kx_flash_attention_f16out(const float* query, const float* key_cache, const 
                               int32_t head_size, int32_t seq_len, int32_t pos, int32_t layer_idx,
                               float softmax_scale, int32_t is_causal, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* kx_flash_attention_f32 / _f16out over a 16-bit KV cache (see kx_mha_decode_kv16).  Exactly one
+ * of out (fp32 rows) and out16 (fp16 rows) is non-null; Tq > 1 needs the workspace of
+ * kx_flash_attention_workspace_bytes() (the kernel works from per-head copies). */
+int kx_flash_attention_kv16(const float* query, const void* key_cache16, const void* value_cache16,
+                            float* out, void* out16, int32_t Tq, int32_t head_num,
+                            int32_t kv_head_num, int32_t head_size, int32_t seq_len, int32_t pos,
+                            int32_t layer_idx, float softmax_scale, int32_t is_causal,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* Workspace for Tq > 1 that lets the kernel work from fp16 copies of the layer's K/V rows 0..pos
  * (made once per call).  The first 16 KiB are left untouched, so the decode workspace, grown to
  * this size, can serve both.  With a smaller workspace each workgroup converts the fp32 rows it
@@ -235,6 +253,10 @@ int kx_flash_attention_f32(const float* query, const float* key_cache, const flo
  * rows of `dim`. */
 int kx_rmsnorm_f32(const float* in, const float* weight, float* out, int32_t dim, int32_t rows,
                    float eps, void* stream);
+/* Rows of fp32 -> rows of fp16: dst16[r][c] = half(src[r][c]), c < cols (cols % 4 == 0; leading
+ * dimensions in elements).  Used to file prompt K/V rows into a 16-bit KV cache. */
+int kx_f32_to_f16_rows(const float* src, int64_t ld_src, void* dst16, int64_t ld_dst, int32_t cols,
+                       int32_t rows, void* stream);
 /* The same normalisation with fp16 output rows (input of kx_gemm_w8_f16act_ws). */
 int kx_rmsnorm_f16out(const float* in, const float* weight, void* out16, int32_t dim, int32_t rows,
                       float eps, void* stream);

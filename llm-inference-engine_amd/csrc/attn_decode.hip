@@ -55,33 +55,40 @@ struct AttnTile {
   f32x4 v[4][NH];
 };
 
-template <int HS>
-__device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const float* __restrict__ kbase,
-                                               const float* __restrict__ vbase, int key0, int last,
+// four consecutive cache elements as fp32; a 16-bit cache is widened here (exactly)
+__device__ __forceinline__ f32x4 load_kv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load_kv4(const _Float16* p) {
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+template <int HS, typename KVT>
+__device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __restrict__ kbase,
+                                               const KVT* __restrict__ vbase, int key0, int last,
                                                int kv_dim, int n, int g) {
   constexpr int NJ = AttnTile<HS>::NJ, NH = AttnTile<HS>::NH;
   constexpr int DLV = HS >= 64 ? 16 : HS / 4;  // dim-lanes that carry data
   // K: lane (key n, g) loads K[key][16j+4g .. +4)
-  const float* kr = kbase + (size_t)min(key0 + n, last) * kv_dim + 4 * g;
+  const KVT* kr = kbase + (size_t)min(key0 + n, last) * kv_dim + 4 * g;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) T.k[j] = *reinterpret_cast<const f32x4*>(kr + 16 * j);
+  for (int j = 0; j < NJ; ++j) T.k[j] = load_kv4(kr + 16 * j);
   // V: lane (dim-lane n, g) loads V[key0+4g+r][64h+4n .. +4)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float* vr = vbase + (size_t)min(key0 + 4 * g + r, last) * kv_dim + 4 * n;
+    const KVT* vr = vbase + (size_t)min(key0 + 4 * g + r, last) * kv_dim + 4 * n;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       T.v[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (n < DLV) T.v[r][h] = *reinterpret_cast<const f32x4*>(vr + 64 * h);
+      if (n < DLV) T.v[r][h] = load_kv4(vr + 64 * h);
     }
   }
 }
 
 // PREFETCH: a wave with several tiles requests the next one before it consumes the current one
 // (costs a second set of tile registers; pointless when every wave has a single tile).
-template <int HS, bool PREFETCH>
+template <int HS, bool PREFETCH, typename KVT>
 __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
-    const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
+    const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
     const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale) {
   constexpr int NJ = AttnTile<HS>::NJ;  // float4 K loads per lane per tile
@@ -102,14 +109,14 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   const int tiles_per_split = attn_tiles_per_split(ntiles, (int)gridDim.y);
   const int nsplit = (ntiles + tiles_per_split - 1) / tiles_per_split;
   if (split >= nsplit) return;
-  const float* kbase = kc + (size_t)kvh * HS;
-  const float* vbase = vc + (size_t)kvh * HS;
+  const KVT* kbase = kc + (size_t)kvh * HS;
+  const KVT* vbase = vc + (size_t)kvh * HS;
 
   const int t_begin = split * tiles_per_split;
   const int t_end = min(t_begin + tiles_per_split, ntiles);
   int t = t_begin + wave;
   AttnTile<HS> cur;
-  if (t < t_end) attn_load_tile<HS>(cur, kbase, vbase, t << 4, last, kv_dim, n, g);
+  if (t < t_end) attn_load_tile<HS, KVT>(cur, kbase, vbase, t << 4, last, kv_dim, n, g);
 
   // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e]
   float qf[NJ][4];
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     AttnTile<HS> nxt;
     const bool more = t + kAttnWaves < t_end;
     if (PREFETCH && more)
-      attn_load_tile<HS>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
+      attn_load_tile<HS, KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
     // ---- S^T[key][head] = K . Q^T (two independent accumulation chains) ----
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       }
     if (more) {
       if (PREFETCH) cur = nxt;
-      else attn_load_tile<HS>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
+      else attn_load_tile<HS, KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
     }
   }
 
@@ -370,7 +377,8 @@ extern "C" size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size) {
          (size_t)head_num * kx::kMaxSplits * kx::attn_ws_stride(head_size) * sizeof(float);
 }
 
-static int mha_decode_launch(const float* query, const float* key_cache, const float* value_cache,
+template <typename KVT>
+static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT* value_cache,
                              float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
                              int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                              int32_t layer_index, void* workspace, size_t workspace_bytes,
@@ -381,8 +389,9 @@ static int mha_decode_launch(const float* query, const float* key_cache, const f
   const int kvh = head_num / kv_mul;
   if (kv_dim != kvh * head_size) return KX_EINVAL;
   const size_t layer_off = (size_t)layer_index * (size_t)seq_len * (size_t)kv_dim;
-  const float* kc = key_cache + layer_off;
-  const float* vc = value_cache + layer_off;
+  const KVT* kc = key_cache + layer_off;
+  const KVT* vc = value_cache + layer_off;
+  constexpr bool kFp32Cache = sizeof(KVT) == 4;
   const float scale = 1.0f / sqrtf((float)head_size);  // mha_kernel.cu / cpu/mha_kernel.cpp:11
   // one MFMA column block holds the heads of a kv head; the tiled kernel is built for the
   // head sizes of the supported model families
@@ -390,12 +399,13 @@ static int mha_decode_launch(const float* query, const float* key_cache, const f
                      (((uintptr_t)query | (uintptr_t)kc | (uintptr_t)vc) % 16 == 0) &&
                      kv_dim % 4 == 0;
   if (!tiled) {
-    if (pos_dev) return KX_EUNSUPPORTED;
+    if (pos_dev || !kFp32Cache) return KX_EUNSUPPORTED;
     // the score rows sit behind the ticket words so the two paths can share one workspace
     if (!workspace || workspace_bytes < kTicketBytes + (size_t)head_num * seq_len * sizeof(float))
       return KX_EWORKSPACE;
     hipLaunchKernelGGL(attn_decode_generic_kernel, dim3(head_num), dim3(256), 0,
-                       (hipStream_t)stream, query, kc, vc, out,
+                       (hipStream_t)stream, query, reinterpret_cast<const float*>(kc),
+                       reinterpret_cast<const float*>(vc), out,
                        reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes), pos,
                        kv_mul, kv_dim, head_size, seq_len, scale);
     KX_LAUNCH_CHECK();
@@ -427,10 +437,10 @@ static int mha_decode_launch(const float* query, const float* key_cache, const f
 #define KX_ATTN_LAUNCH(HS_)                                                                      \
   do {                                                                                           \
     if (prefetch)                                                                                \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, true>), grid, block, 0, s, query, kc, vc, out, \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT>), grid, block, 0, s, query, kc, vc, out, \
                          ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                      \
     else                                                                                         \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, false>), grid, block, 0, s, query, kc, vc,     \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT>), grid, block, 0, s, query, kc, vc,     \
                          out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                 \
   } while (0)
   switch (head_size) {
@@ -449,7 +459,7 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
                                  int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t kv_dim,
                                  int32_t seq_len, int32_t layer_index, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-  return mha_decode_launch(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
+  return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
                            head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
                            stream);
 }
@@ -461,7 +471,19 @@ extern "C" int kx_mha_decode_dpos_f32(const float* query, const float* key_cache
                                       int32_t seq_len, int32_t layer_index, void* workspace,
                                       size_t workspace_bytes, void* stream) {
   if (!pos_dev) return KX_EINVAL;
-  return mha_decode_launch(query, key_cache, value_cache, out, max_pos, pos_dev, head_num, kv_mul,
+  return mha_decode_launch<float>(query, key_cache, value_cache, out, max_pos, pos_dev, head_num, kv_mul,
                            head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
                            stream);
+}
+
+extern "C" int kx_mha_decode_kv16(const float* query, const void* key_cache16,
+                                  const void* value_cache16, float* out, int32_t pos,
+                                  const int32_t* pos_dev, int32_t head_num, int32_t kv_mul,
+                                  int32_t head_size, int32_t kv_dim, int32_t seq_len,
+                                  int32_t layer_index, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  return mha_decode_launch<_Float16>(query, static_cast<const _Float16*>(key_cache16),
+                                     static_cast<const _Float16*>(value_cache16), out, pos, pos_dev,
+                                     head_num, kv_mul, head_size, kv_dim, seq_len, layer_index,
+                                     workspace, workspace_bytes, stream);
 }

@@ -39,9 +39,15 @@ __device__ __forceinline__ int fa_key_of_pos(int p) {  // swaps bits 2 and 3; it
   return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1);
 }
 
-template <int HS>
-__global__ __launch_bounds__(256) void kv_to_f16_kernel(const float* __restrict__ kc,
-                                                        const float* __restrict__ vc,
+__device__ __forceinline__ f32x4 fa_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 fa_load4(const _Float16* p) {  // 16-bit cache: widened, exact
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+template <int HS, typename KVT>
+__global__ __launch_bounds__(256) void kv_to_f16_kernel(const KVT* __restrict__ kc,
+                                                        const KVT* __restrict__ vc,
                                                         _Float16* __restrict__ k16,
                                                         _Float16* __restrict__ v16t, int kv_dim,
                                                         int pos, int s_pad) {
@@ -52,8 +58,8 @@ __global__ __launch_bounds__(256) void kv_to_f16_kernel(const float* __restrict_
   for (int item = tid; item < FA_KV * (HS / 4); item += 256) {
     const int key = item / (HS / 4), d4 = (item % (HS / 4)) * 4;
     const size_t src = (size_t)min(key0 + key, pos) * kv_dim + (size_t)kvh * HS + d4;
-    const f32x4 kv = *reinterpret_cast<const f32x4*>(kc + src);
-    const f32x4 vv = *reinterpret_cast<const f32x4*>(vc + src);
+    const f32x4 kv = fa_load4(kc + src);
+    const f32x4 vv = fa_load4(vc + src);
     f16x4 h;
     h[0] = (_Float16)kv.x; h[1] = (_Float16)kv.y; h[2] = (_Float16)kv.z; h[3] = (_Float16)kv.w;
     *reinterpret_cast<f16x4*>(k16 + ((size_t)kvh * s_pad + key0 + key) * HS + d4) = h;
@@ -82,6 +88,8 @@ struct FaArgs {
   _Float16* out16;       // when set, the output is written here as fp16 instead of to `out`
   const _Float16* k16;   // fp16 copies (see kv_to_f16_kernel), or null
   const _Float16* v16t;
+  const _Float16* kc16;  // 16-bit cache: the layer's rows (kc / vc are null then)
+  const _Float16* vc16;
   int32_t s_pad;
 };
 
@@ -424,12 +432,18 @@ static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* wor
                           size_t workspace_bytes, hipStream_t s) {
   const int s_pad = (a.pos / FA_KV + 1) * FA_KV;
   const size_t half_bytes = (size_t)kvh * s_pad * HS * 2;
-  if (workspace && workspace_bytes >= FA_WS_SKIP + 2 * half_bytes) {
+  const bool have_ws = workspace && workspace_bytes >= FA_WS_SKIP + 2 * half_bytes;
+  if (a.kc16 && !have_ws) return KX_EWORKSPACE;  // a 16-bit cache is only read through the copies
+  if (have_ws) {
     char* ws = static_cast<char*>(workspace) + FA_WS_SKIP;
     _Float16* k16 = reinterpret_cast<_Float16*>(ws);
     _Float16* v16t = reinterpret_cast<_Float16*>(ws + half_bytes);
-    hipLaunchKernelGGL(kv_to_f16_kernel<HS>, dim3(s_pad / FA_KV, kvh), dim3(256), 0, s, a.kc, a.vc,
-                       k16, v16t, a.kv_dim, a.pos, s_pad);
+    if (a.kc16)
+      hipLaunchKernelGGL((kv_to_f16_kernel<HS, _Float16>), dim3(s_pad / FA_KV, kvh), dim3(256), 0, s,
+                         a.kc16, a.vc16, k16, v16t, a.kv_dim, a.pos, s_pad);
+    else
+      hipLaunchKernelGGL((kv_to_f16_kernel<HS, float>), dim3(s_pad / FA_KV, kvh), dim3(256), 0, s, a.kc,
+                         a.vc, k16, v16t, a.kv_dim, a.pos, s_pad);
     KX_LAUNCH_CHECK();
     a.k16 = k16;
     a.v16t = v16t;
@@ -448,20 +462,25 @@ extern "C" size_t kx_flash_attention_workspace_bytes(int32_t pos, int32_t kv_hea
   return kx::FA_WS_SKIP + 2 * (size_t)kv_head_num * s_pad * head_size * 2;
 }
 
-static int flash_attention_run(const float* query, const float* key_cache, const float* value_cache,
-                               float* out, _Float16* out16, int32_t Tq, int32_t head_num,
+static int flash_attention_run(const float* query, const void* key_cache_any,
+                               const void* value_cache_any, bool kv16, float* out, _Float16* out16,
+                               int32_t Tq, int32_t head_num,
                                int32_t kv_head_num, int32_t head_size, int32_t seq_len, int32_t pos,
                                int32_t layer_idx, float softmax_scale, int32_t is_causal,
                                void* workspace, size_t workspace_bytes, void* stream) {
   using namespace kx;
-  if (!query || !key_cache || !value_cache || (!out && !out16)) return KX_EINVAL;
+  const float* key_cache = kv16 ? nullptr : static_cast<const float*>(key_cache_any);
+  const float* value_cache = kv16 ? nullptr : static_cast<const float*>(value_cache_any);
+  const _Float16* key_cache16 = kv16 ? static_cast<const _Float16*>(key_cache_any) : nullptr;
+  const _Float16* value_cache16 = kv16 ? static_cast<const _Float16*>(value_cache_any) : nullptr;
+  if (!query || !key_cache_any || !value_cache_any || (!out && !out16)) return KX_EINVAL;
   if (Tq <= 0 || head_num <= 0 || kv_head_num <= 0 || head_num % kv_head_num) return KX_EINVAL;
   if (pos < 0 || pos >= seq_len || pos - (Tq - 1) < 0) return KX_EINVAL;
   const int kv_mul = head_num / kv_head_num;
   const int kv_dim = kv_head_num * head_size;
   const float default_scale = 1.0f / sqrtf((float)head_size);
   const bool tiled = (head_size == 32 || head_size == 64 || head_size == 128) &&
-                     (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache |
+                     (((uintptr_t)query | (uintptr_t)key_cache_any | (uintptr_t)value_cache_any |
                        (uintptr_t)out) % 16 == 0);
   if (out16 && (Tq == 1 || !tiled || (uintptr_t)out16 % 8)) return KX_EUNSUPPORTED;
   if (Tq == 1 || !tiled) {
@@ -470,10 +489,13 @@ static int flash_attention_run(const float* query, const float* key_cache, const
     if (fabsf(softmax_scale - default_scale) > 1e-6f * default_scale) return KX_EUNSUPPORTED;
     for (int32_t i = 0; i < Tq; ++i) {
       const int32_t p = is_causal ? pos - (Tq - 1) + i : pos;
-      int rc = kx_mha_decode_f32(query + (size_t)i * head_num * head_size, key_cache, value_cache,
-                                 out + (size_t)i * head_num * head_size, p, head_num, kv_mul,
-                                 head_size, kv_dim, seq_len, layer_idx, workspace, workspace_bytes,
-                                 stream);
+      const float* qi = query + (size_t)i * head_num * head_size;
+      float* oi = out + (size_t)i * head_num * head_size;
+      int rc = kv16 ? kx_mha_decode_kv16(qi, key_cache16, value_cache16, oi, p, nullptr, head_num, kv_mul,
+                                         head_size, kv_dim, seq_len, layer_idx, workspace,
+                                         workspace_bytes, stream)
+                    : kx_mha_decode_f32(qi, key_cache, value_cache, oi, p, head_num, kv_mul, head_size,
+                                        kv_dim, seq_len, layer_idx, workspace, workspace_bytes, stream);
       if (rc) return rc;
     }
     return KX_OK;
@@ -487,7 +509,12 @@ static int flash_attention_run(const float* query, const float* key_cache, const
   const int threads = 64 * hpb * qsubs;
   const size_t layer_off = (size_t)layer_idx * (size_t)seq_len * (size_t)kv_dim;
   FaArgs a{};
-  a.q = query; a.kc = key_cache + layer_off; a.vc = value_cache + layer_off; a.out = out;
+  a.q = query; a.out = out;
+  if (kv16) {
+    a.kc16 = key_cache16 + layer_off; a.vc16 = value_cache16 + layer_off;
+  } else {
+    a.kc = key_cache + layer_off; a.vc = value_cache + layer_off;
+  }
   a.out16 = out16;
   a.Tq = Tq; a.H = head_num; a.kv_mul = kv_mul; a.kv_dim = kv_dim; a.pos = pos;
   a.causal = is_causal ? 1 : 0; a.hpb = hpb; a.qsubs = qsubs; a.scale = softmax_scale;
@@ -507,7 +534,7 @@ extern "C" int kx_flash_attention_f32(const float* query, const float* key_cache
                                       float softmax_scale, int32_t is_causal, void* workspace,
                                       size_t workspace_bytes, void* stream) {
   if (!out) return KX_EINVAL;
-  return flash_attention_run(query, key_cache, value_cache, out, nullptr, Tq, head_num, kv_head_num,
+  return flash_attention_run(query, key_cache, value_cache, false, out, nullptr, Tq, head_num, kv_head_num,
                              head_size, seq_len, pos, layer_idx, softmax_scale, is_causal, workspace,
                              workspace_bytes, stream);
 }
@@ -519,7 +546,19 @@ extern "C" int kx_flash_attention_f16out(const float* query, const float* key_ca
                                          float softmax_scale, int32_t is_causal, void* workspace,
                                          size_t workspace_bytes, void* stream) {
   if (!out16) return KX_EINVAL;
-  return flash_attention_run(query, key_cache, value_cache, nullptr, static_cast<_Float16*>(out16),
+  return flash_attention_run(query, key_cache, value_cache, false, nullptr, static_cast<_Float16*>(out16),
+                             Tq, head_num, kv_head_num, head_size, seq_len, pos, layer_idx,
+                             softmax_scale, is_causal, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kx_flash_attention_kv16(const float* query, const void* key_cache16,
+                                       const void* value_cache16, float* out, void* out16, int32_t Tq,
+                                       int32_t head_num, int32_t kv_head_num, int32_t head_size,
+                                       int32_t seq_len, int32_t pos, int32_t layer_idx,
+                                       float softmax_scale, int32_t is_causal, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  if ((out == nullptr) == (out16 == nullptr)) return KX_EINVAL;  // exactly one output form
+  return flash_attention_run(query, key_cache16, value_cache16, true, out, static_cast<_Float16*>(out16),
                              Tq, head_num, kv_head_num, head_size, seq_len, pos, layer_idx,
                              softmax_scale, is_causal, workspace, workspace_bytes, stream);
 }

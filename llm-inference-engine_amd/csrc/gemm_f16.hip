@@ -36,9 +36,9 @@ struct GemmF16Args {
   int32_t T, M, K;
 };
 
-// X fp32 [T][ldx] -> fp16 [T][M]
+// X fp32 [T][ldx] -> fp16 [T][ldy], M columns
 __global__ void f32_to_f16_rows_kernel(const float* __restrict__ x, int64_t ldx,
-                                       _Float16* __restrict__ y, int M, int64_t n4) {
+                                       _Float16* __restrict__ y, int64_t ldy, int M, int64_t n4) {
   const int m4 = M / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -47,7 +47,7 @@ __global__ void f32_to_f16_rows_kernel(const float* __restrict__ x, int64_t ldx,
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * ldx + c);
     f16x4 h;
     h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-    *reinterpret_cast<f16x4*>(y + t * M + c) = h;
+    *reinterpret_cast<f16x4*>(y + t * ldy + c) = h;
   }
 }
 
@@ -531,6 +531,18 @@ extern "C" size_t kx_gemm_w8_workspace_bytes(int32_t T, int32_t M, int32_t K) {
   return kx::align256((size_t)T * M * 2) + kx::align256((size_t)K * M * 2) + kx::align256((size_t)K * 4);
 }
 
+extern "C" int kx_f32_to_f16_rows(const float* src, int64_t ld_src, void* dst16, int64_t ld_dst,
+                                  int32_t cols, int32_t rows, void* stream) {
+  if (!src || !dst16 || cols <= 0 || rows <= 0 || ld_src < cols || ld_dst < cols) return KX_EINVAL;
+  if (cols % 4 || ld_src % 4 || ld_dst % 4 || (uintptr_t)src % 16 || (uintptr_t)dst16 % 8) return KX_EINVAL;
+  const int64_t n4 = (int64_t)rows * (cols / 4);
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(kx::f32_to_f16_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                     ld_src, static_cast<_Float16*>(dst16), ld_dst, cols, n4);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
 extern "C" size_t kx_gemm_w8_f16act_workspace_bytes(int32_t M, int32_t K) {
   if (M <= 0 || K <= 0) return 0;
   return kx::align256((size_t)K * M * 2) + kx::align256((size_t)K * 4);
@@ -630,7 +642,7 @@ extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, c
   char* ws = static_cast<char*>(workspace);
   _Float16* x16 = reinterpret_cast<_Float16*>(ws);
   const int64_t n4 = (int64_t)T * (M / 4);
-  hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(2048), dim3(256), 0, s, X, ldx, x16, M, n4);
+  hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(2048), dim3(256), 0, s, X, ldx, x16, (int64_t)M, M, n4);
   KX_LAUNCH_CHECK();
   return gemm_f16act_run(x16, w, scales, group_size, KX_GEMM_ROUTE_F32, nullptr, y0, ld0, y1, ld1, y2,
                          ld2, k0, k1, residual, ldr, T, M, K, ws + align256((size_t)T * M * 2), s);

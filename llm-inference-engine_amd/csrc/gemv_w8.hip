@@ -78,6 +78,21 @@ __device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, flo
   }
 }
 
+// Row of the stacked q|k|v product -> its destination; k and v rows go to the position's cache row,
+// rounded to fp16 when the cache holds fp16.
+__device__ __forceinline__ void store_routed(const GemvW8Args& a, int row, int pos, float v) {
+  if (a.kv_f16 && row >= a.k0) {
+    const bool is_k = row < a.k1;
+    _Float16* dst = reinterpret_cast<_Float16*>(is_k ? a.y1 : a.y2) + (size_t)pos * a.kv_pos_stride;
+    dst[row - (is_k ? a.k0 : a.k1)] = (_Float16)v;
+    return;
+  }
+  float* dst;
+  int rr;
+  route(a, row, pos, dst, rr);
+  dst[rr] = v;
+}
+
 // Issues the 128-bit weight loads (and the one scale per load) of U chunks of R rows.
 template <int R, int U, int R2, int U2, int MODE>
 __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, int row_end,
@@ -252,12 +267,8 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
           o0 = t0;
           o1 = t1;
         }
-        float* dst;
-        int rr;
-        route(a, row0, pos, dst, rr);
-        dst[rr] = o0;
-        route(a, row1, pos, dst, rr);
-        dst[rr] = o1;
+        store_routed(a, row0, pos, o0);
+        store_routed(a, row1, pos, o1);
       }
     }
   } else {
@@ -487,6 +498,7 @@ extern "C" int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* d, void* stream) {
       a.pos_dev = d->pos_dev; a.pos_val = d->pos;
       a.rope_variant = d->rope_variant; a.head_size = d->head_size;
       a.kv_pos_stride = d->kv_pos_stride;
+      a.kv_f16 = d->kv_f16;
       break;
     default:
       return KX_EINVAL;

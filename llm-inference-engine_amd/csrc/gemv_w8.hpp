@@ -31,7 +31,8 @@ struct GemvW8Args {
   int32_t pos_val;
   int32_t rope_variant;
   int32_t head_size;
-  int32_t kv_pos_stride;  // y1/y2 are advanced by pos * kv_pos_stride floats (KV-cache row)
+  int32_t kv_pos_stride;  // y1/y2 are advanced by pos * kv_pos_stride elements (KV-cache row)
+  int32_t kv_f16;         // GEMV_QKV_ROPE: y1/y2 point at fp16 cache rows
 };
 
 int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s);

@@ -80,6 +80,11 @@ SIGNATURES = {
                                          _i32, _i32, _vp, _sz, _vp]),
     "kx_flash_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _i32, _f, _i32, _vp, _sz, _vp]),
+    "kx_mha_decode_kv16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+                                     _sz, _vp]),
+    "kx_flash_attention_kv16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                          _f, _i32, _vp, _sz, _vp]),
+    "kx_f32_to_f16_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _i32, _i32, _vp]),
     "kx_rmsnorm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_sin_cos_cache_f32": (C.c_int, [_i32, _i32, _f, _vp, _vp, _vp]),
     "kx_rope_f32": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -273,15 +278,23 @@ def gemv_f32(x, w, scale=1.0):
     return dy.numpy(np.float32, (K,))
 
 
-def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspace_bytes=None):
+def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspace_bytes=None,
+               kv16=False):
+    """kv16: the caches are uploaded as IEEE half (the 16-bit KV cache form)."""
     L, S, kv_dim = kc.shape
-    dq, dk, dv = Buf.from_numpy(q.astype(np.float32)), Buf.from_numpy(kc.astype(np.float32)), \
-        Buf.from_numpy(vc.astype(np.float32))
+    kvt = np.float16 if kv16 else np.float32
+    dq, dk, dv = Buf.from_numpy(q.astype(np.float32)), Buf.from_numpy(kc.astype(kvt)), \
+        Buf.from_numpy(vc.astype(kvt))
     out = Buf.zeros(head_num * head_size)
     if workspace_bytes is None:
         workspace_bytes = max(lib().kx_attn_workspace_bytes(head_num, head_size),
                               16384 + head_num * S * 4)
     ws = Buf.zeros(workspace_bytes, np.uint8) if workspace_bytes else None
+    if kv16:
+        check(lib().kx_mha_decode_kv16(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos, None, head_num, kv_mul,
+                                       head_size, kv_dim, S, layer_index, ws.ptr if ws else None,
+                                       workspace_bytes, None), "kx_mha_decode_kv16")
+        return out.numpy(np.float32, (head_num, head_size))
     check(lib().kx_mha_decode_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos, head_num, kv_mul, head_size,
                                   kv_dim, S, layer_index, ws.ptr if ws else None, workspace_bytes,
                                   None), "kx_mha_decode_f32")
@@ -289,14 +302,14 @@ def mha_decode(q, kc, vc, pos, head_num, kv_mul, head_size, layer_index, workspa
 
 
 def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx, softmax_scale=None,
-                    is_causal=True, f16_copies=True, f16_out=False):
+                    is_causal=True, f16_copies=True, f16_out=False, kv16=False):
     L, S, kv_dim = kc.shape
     q = np.ascontiguousarray(q, np.float32).reshape(-1, head_num, head_size)
     Tq = q.shape[0]
     if softmax_scale is None:
         softmax_scale = float(1.0 / np.sqrt(np.float32(head_size)))
-    dq, dk, dv = Buf.from_numpy(q), Buf.from_numpy(kc.astype(np.float32)), \
-        Buf.from_numpy(vc.astype(np.float32))
+    kvt = np.float16 if kv16 else np.float32
+    dq, dk, dv = Buf.from_numpy(q), Buf.from_numpy(kc.astype(kvt)), Buf.from_numpy(vc.astype(kvt))
     out = Buf.zeros(q.size)
     wsb = max(lib().kx_attn_workspace_bytes(head_num, head_size), 16384 + head_num * S * 4)
     if f16_copies:  # large enough for the fp16 K/V copies of the prefill path
@@ -304,6 +317,14 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
     else:
         wsb = min(wsb, lib().kx_flash_attention_workspace_bytes(pos, kv_head_num, head_size) - 1)
     ws = Buf.zeros(wsb, np.uint8)
+    if kv16:
+        out16 = Buf.zeros(q.size, np.float16) if f16_out else None
+        check(lib().kx_flash_attention_kv16(dq.ptr, dk.ptr, dv.ptr, None if f16_out else out.ptr,
+                                            out16.ptr if f16_out else None, Tq, head_num, kv_head_num,
+                                            head_size, S, pos, layer_idx, softmax_scale,
+                                            1 if is_causal else 0, ws.ptr, wsb, None),
+              "kx_flash_attention_kv16")
+        return out16.numpy(np.float16, q.shape) if f16_out else out.numpy(np.float32, q.shape)
     if f16_out:
         out16 = Buf.zeros(q.size, np.float16)
         check(lib().kx_flash_attention_f16out(dq.ptr, dk.ptr, dv.ptr, out16.ptr, Tq, head_num,

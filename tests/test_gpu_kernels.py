@@ -655,3 +655,86 @@ def test_flash_attention_forced_rescale_and_last_row_equals_decode():
     np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
     last = kx.mha_decode(q[-1].reshape(-1), kc, vc, pos, H, H // KVH, hs, 0)
     np.testing.assert_allclose(got[-1], last, rtol=0, atol=3e-3)
+
+
+# ---------------- 16-bit KV cache ---------------------------------------------------------------------
+@pytest.mark.parametrize("H,KVH,hs,S,pos", [(32, 8, 128, 600, 599), (8, 2, 64, 100, 37), (4, 4, 32, 40, 0),
+                                            (28, 4, 128, 1100, 1099)])
+def test_mha_decode_kv16_equals_fp32_path_on_rounded_cache(H, KVH, hs, S, pos):
+    # K and V are widened exactly, so a half cache must give what the fp32 kernel gives on the
+    # same values; and it stays within fp16 rounding of the unrounded cache (oracle)
+    rng = np.random.default_rng(pos + H)
+    kc = rng.standard_normal((2, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((2, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    k16, v16 = kc.astype(np.float16), vc.astype(np.float16)
+    got = kx.mha_decode(q, k16, v16, pos, H, H // KVH, hs, 1, kv16=True)
+    same = kx.mha_decode(q, k16.astype(np.float32), v16.astype(np.float32), pos, H, H // KVH, hs, 1)
+    np.testing.assert_allclose(got, same, rtol=0, atol=1e-6)
+    want = kxo.mha(pos, H, 1, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    np.testing.assert_allclose(got, want, rtol=0, atol=4e-3)
+
+
+def test_mha_decode_kv16_device_position_and_preconditions():
+    L = kx.lib()
+    rng = np.random.default_rng(2)
+    H, KVH, hs, S = 8, 2, 128, 300
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float16)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float16)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    dq, dk, dv = kx.Buf.from_numpy(q), kx.Buf.from_numpy(kc), kx.Buf.from_numpy(vc)
+    out = kx.Buf.zeros(H * hs)
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    for pos in (0, 17, 299):
+        pd = kx.Buf.from_numpy(np.array([pos], np.int32))
+        kx.check(L.kx_mha_decode_kv16(dq.ptr, dk.ptr, dv.ptr, out.ptr, S - 1, pd.ptr, H, H // KVH, hs,
+                                      KVH * hs, S, 0, ws.ptr, wsb, None))
+        want = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0, kv16=True)
+        np.testing.assert_allclose(out.numpy(np.float32, (H, hs)), want, rtol=0, atol=1e-6)
+    # head size the tiled kernel is not built for: the generic fp32 kernel does not read half rows
+    assert L.kx_mha_decode_kv16(dq.ptr, dk.ptr, dv.ptr, out.ptr, 3, None, 8, 4, 16, 32, 64, 0, ws.ptr,
+                                wsb, None) == -2
+    assert L.kx_mha_decode_kv16(dq.ptr, None, dv.ptr, out.ptr, 3, None, H, H // KVH, hs, KVH * hs, S, 0,
+                                ws.ptr, wsb, None) == -1
+
+
+@pytest.mark.parametrize("H,KVH,hs,S,pos,Tq", [(8, 2, 128, 300, 299, 300), (8, 2, 64, 200, 150, 33),
+                                               (4, 2, 32, 70, 69, 70)])
+def test_flash_attention_kv16(H, KVH, hs, S, pos, Tq):
+    rng = np.random.default_rng(Tq)
+    kc = rng.standard_normal((2, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((2, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal((Tq, H, hs)).astype(np.float32)
+    k16, v16 = kc.astype(np.float16), vc.astype(np.float16)
+    got = kx.flash_attention(q, k16, v16, H, KVH, hs, pos, 1, kv16=True)
+    # the prefill kernel rounds K and V to fp16 anyway: identical to the fp32-cache path on the
+    # rounded values
+    same = kx.flash_attention(q, k16.astype(np.float32), v16.astype(np.float32), H, KVH, hs, pos, 1)
+    np.testing.assert_array_equal(got, same)
+    want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, 1, threads=8)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
+    got16 = kx.flash_attention(q, k16, v16, H, KVH, hs, pos, 1, kv16=True, f16_out=True)
+    np.testing.assert_allclose(got16.astype(np.float32), got, rtol=2.0 ** -10, atol=1e-6)
+    # without the workspace for the per-head copies the half cache cannot be read
+    L = kx.lib()
+    dq, dk, dv = kx.Buf.from_numpy(q), kx.Buf.from_numpy(k16), kx.Buf.from_numpy(v16)
+    out = kx.Buf.zeros(q.size)
+    ws = kx.Buf.zeros(32768, np.uint8)
+    assert L.kx_flash_attention_kv16(dq.ptr, dk.ptr, dv.ptr, out.ptr, None, Tq, H, KVH, hs, S, pos, 1,
+                                     float(1 / np.sqrt(hs)), 1, ws.ptr, 20000, None) == -3
+    assert L.kx_flash_attention_kv16(dq.ptr, dk.ptr, dv.ptr, None, None, Tq, H, KVH, hs, S, pos, 1,
+                                     float(1 / np.sqrt(hs)), 1, ws.ptr, 32768, None) == -1
+
+
+def test_f32_to_f16_rows_strided():
+    rng = np.random.default_rng(0)
+    rows, cols, lds, ldd = 37, 64, 80, 96
+    src = rng.standard_normal((rows, lds)).astype(np.float32)
+    d_src = kx.Buf.from_numpy(src)
+    d_dst = kx.Buf.from_numpy(np.full((rows, ldd), 7, np.float16))
+    kx.check(kx.lib().kx_f32_to_f16_rows(d_src.ptr, lds, d_dst.ptr, ldd, cols, rows, None))
+    got = d_dst.numpy(np.float16, (rows, ldd))
+    np.testing.assert_array_equal(got[:, :cols], src[:, :cols].astype(np.float16))
+    assert np.all(got[:, cols:] == 7)
+    assert kx.lib().kx_f32_to_f16_rows(d_src.ptr, lds, d_dst.ptr, ldd, 62, rows, None) == -1
