@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-kernels", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--kv-dtype", choices=["f32", "f16"], default="f32",
+                    help="f32: the reference's cache layout (the headline configuration); f16: the "
+                         "16-bit KV cache option (one fp16 rounding of every stored K/V element)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,7 +187,8 @@ def main():
     shape = host.MODEL_SHAPES[args.model]
     seq_len = args.context + args.warmup + args.steps + args.profile_steps + 64
     seq_len = (seq_len + 63) // 64 * 64
-    model = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, **shape)
+    kv16 = args.kv_dtype == "f16"
+    model = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, kv_f16=kv16, **shape)
     model.init_synthetic(1234)
     if world > 1:
         ids = [host.comm_unique_id() if rank == 0 else None]
@@ -254,7 +258,7 @@ def main():
         bpt = model.linear_bytes_per_token() * world  # whole-model linear bytes per token
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
         kv_bytes = 2 * shape["layer_num"] * (args.context + args.warmup + args.steps // 2) * \
-            (shape["dim"] // shape["head_num"] * shape["kv_head_num"]) * 4
+            (shape["dim"] // shape["head_num"] * shape["kv_head_num"]) * (2 if kv16 else 4)
         tok_s = args.steps / elapsed
         line = {
             "metric": "decode tok/s, W8A16 group-quant, batch 1 (W8A16 GEMV HBM GB/s in roofline)",
@@ -271,7 +275,7 @@ def main():
             "data": "synthetic (seeded random-init weights generated on device, random token ids)",
             "config": {
                 "workload": f"{args.model} W8A16 (group 64) greedy decode, batch 1, "
-                            f"{args.context}-token context, fp32 KV cache",
+                            f"{args.context}-token context, {'fp16' if kv16 else 'fp32'} KV cache",
                 "parallelism": f"tp{world}",
                 "context": args.context,
                 "graph_replay": use_graph,

@@ -55,6 +55,7 @@ enum class DataType : uint8_t {
   kDataTypeFp32 = 1,
   kDataTypeInt8 = 2,
   kDataTypeInt32 = 3,
+  kDataTypeFp16 = 4,  // IEEE half; KV cache rows only (not a reference dtype, base.h:25-30)
 };
 
 inline size_t DataTypeSize(DataType t) {
@@ -62,6 +63,7 @@ inline size_t DataTypeSize(DataType t) {
     case DataType::kDataTypeFp32: return 4;
     case DataType::kDataTypeInt8: return 1;
     case DataType::kDataTypeInt32: return 4;
+    case DataType::kDataTypeFp16: return 2;
     default: return 0;
   }
 }

@@ -19,6 +19,7 @@ typedef struct kxm_config {
   float rope_theta;
   float rms_eps;
   int32_t tp_size, tp_rank;
+  int32_t kv_f16;       /* non-zero: 16-bit (IEEE half) KV cache instead of the reference's fp32 one */
 } kxm_config;
 
 const char* kxm_last_error(void);

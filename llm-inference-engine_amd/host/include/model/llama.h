@@ -55,6 +55,9 @@ struct TransformerConfig {
   float rope_theta = 10000.f;
   float rms_eps = 1e-5f;
   int32_t tp_size = 1, tp_rank = 0;
+  // 16-bit KV cache: rows are kept as IEEE half (one rounding per stored element); the fused token
+  // loop and the batched prompt pass support it, the layer-by-layer loop (fp32 views) does not
+  bool kv_f16 = false;
   // derived (model.cpp:132-134)
   int32_t kv_dim = 0, kv_mul = 0, head_size = 0;
   // per-rank sizes under tensor parallelism

@@ -37,6 +37,7 @@ void* kxm_create(const kxm_config* c) {
   t.seq_len = c->seq_len; t.group_size = c->group_size; t.rope_variant = c->rope_variant;
   t.rope_theta = c->rope_theta; t.rms_eps = c->rms_eps;
   t.tp_size = c->tp_size < 1 ? 1 : c->tp_size; t.tp_rank = c->tp_rank;
+  t.kv_f16 = c->kv_f16 != 0;
   auto* m = new model::LlamaModel();
   base::Status s = m->init(t);
   if (!s) {

@@ -2,6 +2,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "kx_hip.h"
 #include "op/kernels/kernels_interface.h"
@@ -182,6 +183,7 @@ base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
   kvc.layer_num = cfg_.layer_num;
   kvc.kv_head_num = cfg_.kv_head_local;
   kvc.kv_dim = cfg_.kv_dim_local;
+  kvc.dtype = cfg_.kv_f16 ? base::DataType::kDataTypeFp16 : base::DataType::kDataTypeFp32;
   kv_ = std::make_unique<base::KVCacheManager>(kHip, kvc);
   ST_RET(kv_->allocate());
   KX_RET(kx_stream_sync(hip_->stream));
@@ -544,6 +546,7 @@ base::Status LlamaModel::forward_layers(int32_t token, int32_t pos, float* logit
   RefLayers& R = *ref_;
   const TransformerConfig& c = cfg_;
   if (pos < 0 || pos >= c.seq_len) return base::error::InvalidArgument("pos outside seq_len");
+  if (c.kv_f16) return base::error::FunctionNotImplement("the layer-by-layer loop reads an fp32 KV cache");
   auto& buf = R.buffers;
   R.pos_tensor.index<int32_t>(0) = pos;
   R.token_tensor.index<int32_t>(0) = token;
@@ -614,6 +617,7 @@ base::Status LlamaModel::gemv(const Linear& l, int mode, const float* x, const f
     d.rope_variant = cfg_.rope_variant;
     d.head_size = cfg_.head_size;
     d.kv_pos_stride = cfg_.kv_dim_local;
+    d.kv_f16 = cfg_.kv_f16 ? 1 : 0;
   }
   if (prof_on_) {
     ++prof_launches_;
@@ -648,7 +652,11 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
     auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
     ST_RET(gemv(lw.qkv, KX_GEMV_QKV_ROPE, x_, lw.attn_norm, q_, static_cast<float*>(k_ptr),
                 static_cast<float*>(v_ptr), ql, ql + kl, nullptr, st));
-    if (all)
+    if (all && c.kv_f16)
+      KX_RET(kx_mha_decode_kv16(q_, kv_->get_raw_buffer_k(), kv_->get_raw_buffer_v(), att_,
+                                c.seq_len - 1, pos_dev_, c.head_local, c.kv_mul, c.head_size, kl,
+                                c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes, st));
+    else if (all)
       KX_RET(kx_mha_decode_dpos_f32(q_, static_cast<float*>(kv_->get_raw_buffer_k()),
                                     static_cast<float*>(kv_->get_raw_buffer_v()), att_, pos_dev_,
                                     c.seq_len - 1, c.head_local, c.kv_mul, c.head_size, kl,
@@ -750,7 +758,10 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   const int32_t chunk = n < kPrefillChunk ? n : kPrefillChunk;
   // scratch: X, XN [chunk][dim]; Q, ATT [chunk][ql]; H13 [chunk][2hl]; HH [chunk][hl]; then the
   // fp16 workspace of the two-pass GEMM, sized for the widest matrix of a layer
-  const size_t act_bytes = (size_t)chunk * (2 * (size_t)dim + 2 * (size_t)ql + 3 * (size_t)hl) * 4;
+  // with a 16-bit cache the K/V rows of a chunk pass through fp32 scratch (RoPE runs there) and
+  // are rounded into the cache afterwards: KR, VR [chunk][kl]
+  const size_t act_bytes =
+      (size_t)chunk * (2 * (size_t)dim + 2 * (size_t)ql + 3 * (size_t)hl + (c.kv_f16 ? 2 * (size_t)kl : 0)) * 4;
   const size_t act_pad = (act_bytes + 255) / 256 * 256;
   size_t gemm_ws = 0;
   for (size_t b : {kx_gemm_w8_workspace_bytes(chunk, dim, ql + 2 * kl),
@@ -774,13 +785,37 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   float* ATT = Q + (size_t)chunk * ql;
   float* H13 = ATT + (size_t)chunk * ql;
   float* HH = H13 + (size_t)chunk * 2 * hl;
+  float* KR = HH + (size_t)chunk * hl;  // only with a 16-bit cache
+  float* VR = KR + (size_t)chunk * kl;
   void* gws = reinterpret_cast<char*>(pf_) + act_pad;
   const int gs = c.group_size;
   KX_RET(kx_stream_sync(st));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
-  float* kbase = static_cast<float*>(kv_->get_raw_buffer_k());
+  float* kbase = static_cast<float*>(kv_->get_raw_buffer_k());  // half rows when c.kv_f16
   float* vbase = static_cast<float*>(kv_->get_raw_buffer_v());
   const float* res = c.plan.carries_residual ? X : nullptr;
+  // attention over the cache in either element type; out16 selects fp16 output rows
+  auto attention = [&](float* out32, void* out16, int32_t rows_, int32_t last_pos, int32_t layer) -> int {
+    const float scale = 1.0f / std::sqrt((float)c.head_size);
+    if (c.kv_f16)
+      return kx_flash_attention_kv16(Q, kbase, vbase, out32, out16, rows_, c.head_local, c.kv_head_local,
+                                     c.head_size, c.seq_len, last_pos, layer, scale, 1,
+                                     hip_->attn_workspace, hip_->attn_workspace_bytes, st);
+    if (out16)
+      return kx_flash_attention_f16out(Q, kbase, vbase, out16, rows_, c.head_local, c.kv_head_local,
+                                       c.head_size, c.seq_len, last_pos, layer, scale, 1,
+                                       hip_->attn_workspace, hip_->attn_workspace_bytes, st);
+    return kx_flash_attention_f32(Q, kbase, vbase, out32, rows_, c.head_local, c.kv_head_local,
+                                  c.head_size, c.seq_len, last_pos, layer, scale, 1,
+                                  hip_->attn_workspace, hip_->attn_workspace_bytes, st);
+  };
+  // files the chunk's finished K/V rows into a 16-bit cache
+  auto file_kv16 = [&](void* k_ptr, void* v_ptr, int32_t p0_, int32_t rows_) -> int {
+    uint16_t* k16 = static_cast<uint16_t*>(k_ptr) + (size_t)p0_ * kl;
+    uint16_t* v16 = static_cast<uint16_t*>(v_ptr) + (size_t)p0_ * kl;
+    if (int rc = kx_f32_to_f16_rows(KR, kl, k16, kl, kl, rows_, st)) return rc;
+    return kx_f32_to_f16_rows(VR, kl, v16, kl, kl, rows_, st);
+  };
   // shapes the fp16 kernels are built for (LDS-DMA K-steps of 64, 32-unit SwiGLU blocks)
   const bool f16_ok = (gs & (gs - 1)) == 0 && gs >= 16 && dim % 64 == 0 && ql % 64 == 0 &&
                       hl % 64 == 0 && dim % gs == 0 && ql % gs == 0 && hl % gs == 0 &&
@@ -793,8 +828,8 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     for (int32_t l = 0; l < c.layer_num; ++l) {
       const LayerWeights& lw = layers_[l];
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
-      float* krow = static_cast<float*>(k_ptr) + (size_t)p0 * kl;
-      float* vrow = static_cast<float*>(v_ptr) + (size_t)p0 * kl;
+      float* krow = c.kv_f16 ? KR : static_cast<float*>(k_ptr) + (size_t)p0 * kl;
+      float* vrow = c.kv_f16 ? VR : static_cast<float*>(v_ptr) + (size_t)p0 * kl;
       if (f16_chunk) {
         // long chunks keep the GEMM inputs in fp16: the norm and the attention kernel write fp16,
         // SwiGLU runs in the epilogue of the W1|W3 GEMM; XN / ATT / HH are reused as fp16 rows
@@ -803,10 +838,8 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
                                     KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
                                     nullptr, 0, rows, dim, lw.qkv.rows, gws, gemm_ws, st));
         KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
-        KX_RET(kx_flash_attention_f16out(Q, kbase, vbase, ATT, rows, c.head_local, c.kv_head_local,
-                                         c.head_size, c.seq_len, p0 + rows - 1, l,
-                                         1.0f / std::sqrt((float)c.head_size), 1, hip_->attn_workspace,
-                                         hip_->attn_workspace_bytes, st));
+        if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
+        KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
         KX_RET(kx_gemm_w8_f16act_ws(ATT, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs,
                                     KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim,
                                     res, dim, rows, ql, dim, gws, gemm_ws, st));
@@ -826,10 +859,8 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
                                krow, kl, vrow, kl, ql, ql + kl, nullptr, 0, rows, dim,
                                lw.qkv.rows, gws, gemm_ws, st));
       KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
-      KX_RET(kx_flash_attention_f32(Q, kbase, vbase, ATT, rows, c.head_local, c.kv_head_local,
-                                    c.head_size, c.seq_len, p0 + rows - 1, l,
-                                    1.0f / std::sqrt((float)c.head_size), 1, hip_->attn_workspace,
-                                    hip_->attn_workspace_bytes, st));
+      if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
+      KX_RET(attention(ATT, nullptr, rows, p0 + rows - 1, l));
       KX_RET(kx_gemm_w8_f32_ws(ATT, ql, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs, X, dim,
                                nullptr, 0, nullptr, 0, dim, dim, res, dim, rows, ql, dim, gws,
                                gemm_ws, st));
@@ -871,14 +902,46 @@ base::Status LlamaModel::read_state(int32_t* token, int32_t* pos) const {
   return base::error::Success();
 }
 
+// IEEE half -> float on the host (test / inspection helper only)
+static float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else {  // subnormal: normalise
+      int e = -1;
+      do { ++e; man <<= 1; } while (!(man & 0x400u));
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7F800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+
 base::Status LlamaModel::read_kv(int32_t layer, int32_t rows, float* k_host, float* v_host) const {
   if (layer < 0 || layer >= cfg_.layer_num || rows < 0 || rows > cfg_.seq_len)
     return base::error::InvalidArgument("bad kv range");
   auto [k_ptr, v_ptr] = kv_->get_cache_ptr(layer);
   KX_RET(kx_stream_sync(hip_->stream));
-  const size_t n = (size_t)rows * cfg_.kv_dim_local * 4;
-  if (k_host) KX_RET(kx_memcpy_d2h(k_host, k_ptr, n, nullptr));
-  if (v_host) KX_RET(kx_memcpy_d2h(v_host, v_ptr, n, nullptr));
+  const size_t count = (size_t)rows * cfg_.kv_dim_local;
+  if (!cfg_.kv_f16) {
+    if (k_host) KX_RET(kx_memcpy_d2h(k_host, k_ptr, count * 4, nullptr));
+    if (v_host) KX_RET(kx_memcpy_d2h(v_host, v_ptr, count * 4, nullptr));
+    return base::error::Success();
+  }
+  std::vector<uint16_t> tmp(count);
+  for (int which = 0; which < 2; ++which) {
+    float* dst = which ? v_host : k_host;
+    if (!dst || count == 0) continue;
+    KX_RET(kx_memcpy_d2h(tmp.data(), which ? v_ptr : k_ptr, count * 2, nullptr));
+    for (size_t i = 0; i < count; ++i) dst[i] = half_bits_to_float(tmp[i]);
+  }
   return base::error::Success();
 }
 

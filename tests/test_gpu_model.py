@@ -282,6 +282,90 @@ def test_single_rank_communicator_runs_the_allreduce_path():
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
 
 
+# ---------------- 16-bit KV cache -------------------------------------------------------------------
+@pytest.mark.parametrize("n", [40, 300])
+def test_kv16_model_tracks_the_fp32_cache_model(n):
+    # Same weights, fp32 cache vs IEEE-half cache: layer 0's rows are the fp32 rows rounded once
+    # (the same values go in), deeper layers and the logits stay within the rounding's reach, and
+    # the batched prompt pass, eager steps and graph replay agree with each other.
+    shape = dict(dim=512, hidden_dim=1024, layer_num=3, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    seq_len = n + 40
+    toks = np.random.default_rng(n).integers(0, 1000, n).astype(np.int32)
+    ref = host.Model(seq_len=seq_len, group_size=GS, **shape)
+    ref.init_synthetic(4)
+    m = host.Model(seq_len=seq_len, group_size=GS, kv_f16=True, **shape)
+    m.init_synthetic(4)
+    want_last = ref.prefill(toks)
+    got_last = m.prefill(toks)
+    assert np.abs(got_last - want_last).max() <= 1e-2 * np.abs(want_last).max()
+    for layer in range(3):
+        kf, vf = ref.read_kv(layer, n)
+        k, v = m.read_kv(layer, n)
+        if layer == 0:
+            np.testing.assert_array_equal(k, kf.astype(np.float16).astype(np.float32))
+            np.testing.assert_array_equal(v, vf.astype(np.float16).astype(np.float32))
+        else:
+            assert np.abs(k - kf).max() <= 1e-2 * np.abs(kf).max()
+            assert np.abs(v - vf).max() <= 1e-2 * np.abs(vf).max()
+    # the sequential prompt pass (fused decode steps) files the same kind of rows
+    m2 = host.Model(seq_len=seq_len, group_size=GS, kv_f16=True, **shape)
+    m2.init_synthetic(4)
+    seq_last = m2.prefill(toks, exact=True)
+    assert np.abs(seq_last - want_last).max() <= 1e-2 * np.abs(want_last).max()
+    k0, v0 = m2.read_kv(0, n)
+    kf, vf = ref.read_kv(0, n)
+    # layer 0 again, now from the GEMV epilogue: fp32 GEMV vs the MFMA prompt GEMM differ by the
+    # GEMM's own operand rounding, so compare with that tolerance
+    assert np.abs(k0 - kf).max() <= 4e-3 * np.abs(kf).max()
+    # eager and graph-replayed decode from the same state give the same tokens
+    m.decode(8, use_graph=False)
+    eager = m.history(n + 9)
+    m3 = host.Model(seq_len=seq_len, group_size=GS, kv_f16=True, **shape)
+    m3.init_synthetic(4)
+    m3.prefill(toks)
+    m3.decode(8, use_graph=True)
+    np.testing.assert_array_equal(m3.history(n + 9), eager)
+    with pytest.raises(kx.KxError):
+        m.forward_layers(1, 0)   # the layer-by-layer loop reads fp32 cache views
+    for mm in (ref, m, m2, m3):
+        mm.close()
+
+
+def test_kv16_under_tensor_parallel_shards():
+    # every rank rounds its own kv heads' rows: the sharded half cache is the column slice of the
+    # unsharded one, and the logits differ only by the re-association of the row-parallel sums
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    seq_len, tp = 320, 2
+    rng = np.random.default_rng(9)
+    prompt = rng.integers(0, 700, 270).astype(np.int32)
+    one = host.Model(seq_len=seq_len, group_size=GS, kv_f16=True, **shape)
+    one.init_synthetic(21)
+    ref_last = one.prefill(prompt)
+    one.decode(4, use_graph=False)
+    group = host.loopback_create(tp)
+    ranks = [host.Model(seq_len=seq_len, group_size=GS, tp_size=tp, tp_rank=r, kv_f16=True, **shape)
+             for r in range(tp)]
+    for m in ranks:
+        m.init_synthetic(21)
+        m.join_loopback(group)
+    outs = _run_ranks(ranks, lambda r, m: (m.prefill(prompt), m.decode(4, use_graph=False),
+                                           m.history(len(prompt) + 5)))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    assert np.abs(outs[0][0] - ref_last).max() <= 2e-3 * np.abs(ref_last).max()
+    kvl = ranks[0].kv_dim_local
+    kf, vf = one.read_kv(0, len(prompt))
+    for r, m in enumerate(ranks):
+        k, v = m.read_kv(0, len(prompt))
+        np.testing.assert_array_equal(k, kf[:, r * kvl:(r + 1) * kvl])   # layer 0: same inputs, same rounding
+        np.testing.assert_array_equal(v, vf[:, r * kvl:(r + 1) * kvl])
+    for m in ranks:
+        m.close()
+    one.close()
+    host.loopback_destroy(group)
+
+
 def test_fused_path_refuses_fp32_weights():
     m = host.Model(seq_len=8, group_size=0, **TINY)
     m.init_synthetic(1)
