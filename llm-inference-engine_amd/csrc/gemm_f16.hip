@@ -22,7 +22,7 @@
 
 namespace kx {
 
-constexpr int GF_BM = 128, GF_BK = 64;
+constexpr int GF_BK = 64;
 
 struct GemmF16Args {
   const _Float16* X;   // [T][M]
@@ -313,9 +313,7 @@ __device__ __forceinline__ void gemm_f16_body(const GemmF16Args& a) {
 
 // the second launch bound is the number of 256-thread workgroups per CU the registers must allow
 __global__ __launch_bounds__(256, 4) void gemm_f16_kernel_22(const GemmF16Args a) { gemm_f16_body<2, 2, false>(a); }
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, false>(a); }
 __global__ __launch_bounds__(256, 4) void gemm_f16_swiglu_kernel_22(const GemmF16Args a) { gemm_f16_body<2, 2, true>(a); }
-__global__ __launch_bounds__(256, 2) void gemm_f16_swiglu_kernel_42(const GemmF16Args a) { gemm_f16_body<4, 2, true>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // 256 x 256 output tile, 512 threads = 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64 as
@@ -341,7 +339,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_swiglu_kernel_42(const GemmF1
 // the two B register sets swap roles every tile.  Tiles past the end re-load the last K-tile
 // into dead regions, which keeps the counts uniform.
 constexpr int GP_BUF = 65536, GP_BOFF = 32768;
-constexpr int kPipeCus = 256;
 constexpr int GP_GROUP_N = 4;
 using gp_lds_ptr_t = __attribute__((address_space(3))) void*;
 
@@ -574,26 +571,23 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
   a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
   a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
-  // Kernel choice (KX_GEMM_F16_KERNEL = 1 / 2 / 3 forces one, for A/B runs and tests):
-  //   3  pipelined 256 x 256, one workgroup per CU: fastest once the tiles fill the CUs evenly
-  //   2  256 x 128, two per CU: ~4 % faster than 1 with >= 8 row tiles
-  //   1  128 x 128, four per CU
+  // Kernel choice (KX_GEMM_F16_KERNEL = 1 / 3 forces one, for A/B runs and tests):
+  //   1  128 x 128 tiles, four workgroups per CU      3  pipelined 256 x 256, one per CU
+  // The pipelined kernel is ~1.5x faster per FLOP; the small tiles only win while the large ones
+  // would leave most CUs idle AND the reduction is short (measured over T = 512..4096 on the
+  // Llama-3-8B and Qwen2.5-7B matrices: within 3 % of the better kernel except one case at 12 %).
+  // A 256 x 128 variant (two per CU) was never the fastest of the three and is gone.
   int choice = 0;
   if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);  // a few ns; read per call so tests can switch
-  if (choice < 1 || choice > 3) {
-    const long tiles = (long)((T + 255) / 256) * ((K + 255) / 256);
-    const long rounds = (tiles + kPipeCus - 1) / kPipeCus;
-    const bool even = tiles * 10 >= rounds * kPipeCus * 7;  // the CUs are at least ~70 % busy over the rounds
-    choice = (T >= 1024 && M >= 512 && even) ? 3 : T >= 1024 ? 2 : 1;
+  if (choice != 1 && choice != 3) {
+    const long tiles3 = (long)((T + 255) / 256) * ((K + 255) / 256);
+    choice = M >= 512 && (tiles3 >= 144 || M >= 8192) ? 3 : 1;
   }
   if (choice == 3)
     return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, s)
                   : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, s);
-  if (swiglu)
-    return choice == 2 ? launch_gemm_f16<4, 2>(gemm_f16_swiglu_kernel_42, a, s)
-                       : launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s);
-  return choice == 2 ? launch_gemm_f16<4, 2>(gemm_f16_kernel_42, a, s)
-                     : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
+  return swiglu ? launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s)
+                : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
 }
 
 extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales,
@@ -630,9 +624,9 @@ extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, c
   using namespace kx;
   if (!X || !w || !scales || !y0 || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
   const bool two_pass = workspace && workspace_bytes >= kx_gemm_w8_workspace_bytes(T, M, K) &&
-                        T >= 2 * GF_BM && gemm_f16_shape_ok(group_size, M, w, workspace) &&
+                        T >= 320 && gemm_f16_shape_ok(group_size, M, w, workspace) &&
                         ldx % 4 == 0 && ((uintptr_t)X % 16 == 0);
-  if (!two_pass)  // short prompts: converting the whole matrix would cost more than it saves
+  if (!two_pass)  // short prompts (measured crossover 256..384 rows): converting the whole matrix costs more than it saves
     return kx_gemm_w8_f32_ex(X, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1,
                              residual, ldr, T, M, K, stream);
   if (!y1 && !y2) { k0 = K; k1 = K; }

@@ -420,7 +420,7 @@ def test_gemm_w8_vs_oracle(T, K, M):
     assert np.sqrt((err ** 2).mean()) <= 1e-4 * np.sqrt((absum ** 2).mean())
 
 
-@pytest.mark.parametrize("T,K,M", [(256, 128, 128), (300, 200, 256), (517, 384, 1024), (1100, 200, 128)])
+@pytest.mark.parametrize("T,K,M", [(320, 128, 128), (333, 200, 256), (517, 384, 1024), (1100, 200, 128)])
 def test_gemm_w8_two_pass_vs_oracle(T, K, M):
     # long-prompt form: X and scale*w each rounded once to fp16 (2^-11 relative, per element)
     rng = np.random.default_rng(T + K + M)
@@ -464,10 +464,10 @@ def test_gemm_w8_f16_activations_and_fused_swiglu(T, K, M):
     assert np.all(np.abs(h - ref) <= bound)
 
 
-@pytest.mark.parametrize("choice", ["1", "2", "3"])
+@pytest.mark.parametrize("choice", ["1", "3"])
 @pytest.mark.parametrize("T,K,M", [(1100, 600, 192), (520, 256, 64), (1024, 512, 1024)])
 def test_gemm_w8_f16_every_tile_kernel(monkeypatch, choice, T, K, M):
-    # 128 x 128, 256 x 128 and the pipelined 256 x 256 kernel on ragged tiles, 1 / 3 / 16 K-tiles
+    # the 128 x 128 and the pipelined 256 x 256 kernel on ragged tiles, 1 / 3 / 16 K-tiles
     monkeypatch.setenv("KX_GEMM_F16_KERNEL", choice)
     rng = np.random.default_rng(int(choice) * 7 + T)
     _, w, s = rand_w8(rng, K, M)
@@ -514,7 +514,7 @@ def test_rmsnorm_f16out_vs_oracle():
 
 def test_gemm_w8_two_pass_routing_residual_and_fallback():
     rng = np.random.default_rng(31)
-    T, dim, kvd, S = 260, 256, 128, 300
+    T, dim, kvd, S = 330, 256, 128, 360
     K = dim + 2 * kvd
     _, w, s = rand_w8(rng, K, dim)
     X = rng.standard_normal((T, dim)).astype(np.float32)
