@@ -153,7 +153,7 @@ int kx_gemm_w8_f32_ex(const float* X, int64_t ldx, const int8_t* w, const float*
 /* Same contract for long prompts, with a caller-provided workspace of
  * kx_gemm_w8_workspace_bytes(T, M, K) bytes (256-byte aligned): X and the scaled weights are
  * converted to fp16 once per call and the main loop is a plain fp16 MFMA GEMM.  Falls back to
- * kx_gemm_w8_f32_ex when the workspace is missing / too small or T < 320 (below that the
+ * kx_gemm_w8_f32_ex when the workspace is missing / too small or T < 512 (below that the
  * conversion passes cost more than they save). */
 size_t kx_gemm_w8_workspace_bytes(int32_t T, int32_t M, int32_t K);
 int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float* scales,

@@ -624,9 +624,9 @@ extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, c
   using namespace kx;
   if (!X || !w || !scales || !y0 || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
   const bool two_pass = workspace && workspace_bytes >= kx_gemm_w8_workspace_bytes(T, M, K) &&
-                        T >= 320 && gemm_f16_shape_ok(group_size, M, w, workspace) &&
+                        T >= 512 && gemm_f16_shape_ok(group_size, M, w, workspace) &&
                         ldx % 4 == 0 && ((uintptr_t)X % 16 == 0);
-  if (!two_pass)  // short prompts (measured crossover 256..384 rows): converting the whole matrix costs more than it saves
+  if (!two_pass)  // short prompts (the two forms tie at 512..640 rows): converting the whole matrix costs more than it saves
     return kx_gemm_w8_f32_ex(X, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1,
                              residual, ldr, T, M, K, stream);
   if (!y1 && !y2) { k0 = K; k1 = K; }

@@ -76,23 +76,20 @@ __global__ __launch_bounds__(256, 2) void gemm_w8_kernel(const GemmW8Args a) {
 
   auto load_tile = [&](int g) {
     const int kk = g * GM_BK;
+    // rows past the end re-read the last valid row (their outputs are never stored): unconditional
+    // loads keep the whole batch in flight -- a load under a runtime condition makes the compiler
+    // branch around it and drain the counter (270 -> 237 us on 256 x 4096 x 14336)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int t = t0 + xr + 16 * i;
-      xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < a.T) xreg[i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)t * a.ldx + kk + xc);
+      const int t = min(t0 + xr + 16 * i, a.T - 1);
+      xreg[i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)t * a.ldx + kk + xc);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int n = n0 + wrow + 64 * i;
-      wreg[i] = i32x4{0, 0, 0, 0};
-      if (n < a.K)
-        wreg[i] = *reinterpret_cast<const i32x4*>(a.w + (size_t)n * a.M + kk + wchunk);
+      const int n = min(n0 + wrow + 64 * i, a.K - 1);
+      wreg[i] = *reinterpret_cast<const i32x4*>(a.w + (size_t)n * a.M + kk + wchunk);
     }
-    if (tid < GM_BN) {
-      const int n = n0 + tid;
-      sreg = n < a.K ? a.scales[(size_t)n * groups + g] : 0.f;
-    }
+    if (tid < GM_BN) sreg = a.scales[(size_t)min(n0 + tid, a.K - 1) * groups + g];
   };
   auto store_tile = [&](int buf) {
     _Float16* A = lds_a(buf);

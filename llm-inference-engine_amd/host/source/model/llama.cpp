@@ -824,8 +824,9 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   for (int32_t p0 = pos0; p0 < pos0 + n; p0 += rows) {
     rows = pos0 + n - p0 < chunk ? pos0 + n - p0 : chunk;
     KX_RET(kx_embedding_f32(history_dev_ + p0, rows, emb_, dim, c.vocab_size, X, st));
-    // measured crossover of the two forms on the 8B layer matrices: between 256 and 384 rows
-    const bool f16_chunk = f16_ok && rows >= 320;
+    // per-layer GEMM time of the two forms on the 8B matrices ties at 512..640 rows; the fp16 form
+    // also saves the separate SwiGLU pass
+    const bool f16_chunk = f16_ok && rows >= 512;
     for (int32_t l = 0; l < c.layer_num; ++l) {
       const LayerWeights& lw = layers_[l];
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);

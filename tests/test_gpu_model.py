@@ -203,9 +203,9 @@ def test_synthetic_model_fused_and_layer_paths_vs_oracle(shape):
           rope_variant=1, rope_theta=1e6, rms_eps=1e-6), 150),
     (dict(dim=768, hidden_dim=2048, layer_num=1, head_num=12, kv_head_num=12, vocab_size=512,
           rope_variant=0, rope_theta=1e4, rms_eps=1e-5), 64),
-    # 320 rows and more per call: activations stay in fp16 between the kernels of a layer
+    # 512 rows and more per call: activations stay in fp16 between the kernels of a layer
     (dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
-          rope_variant=1, rope_theta=5e5, rms_eps=1e-5), 420),
+          rope_variant=1, rope_theta=5e5, rms_eps=1e-5), 530),
     (dict(dim=512, hidden_dim=1536, layer_num=1, head_num=4, kv_head_num=4, vocab_size=640,
           rope_variant=0, rope_theta=1e4, rms_eps=1e-6), 257),
 ])
@@ -283,7 +283,7 @@ def test_single_rank_communicator_runs_the_allreduce_path():
 
 
 # ---------------- 16-bit KV cache -------------------------------------------------------------------
-@pytest.mark.parametrize("n", [40, 340])
+@pytest.mark.parametrize("n", [40, 530])
 def test_kv16_model_tracks_the_fp32_cache_model(n):
     # Same weights, fp32 cache vs IEEE-half cache: layer 0's rows are the fp32 rows rounded once
     # (the same values go in), deeper layers and the logits stay within the rounding's reach, and
@@ -337,9 +337,9 @@ def test_kv16_under_tensor_parallel_shards():
     # unsharded one, and the logits differ only by the re-association of the row-parallel sums
     shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
                  rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
-    seq_len, tp = 384, 2
+    seq_len, tp = 576, 2
     rng = np.random.default_rng(9)
-    prompt = rng.integers(0, 700, 330).astype(np.int32)
+    prompt = rng.integers(0, 700, 520).astype(np.int32)
     one = host.Model(seq_len=seq_len, group_size=GS, kv_f16=True, **shape)
     one.init_synthetic(21)
     ref_last = one.prefill(prompt)
@@ -402,7 +402,7 @@ def test_tensor_parallel_ranks_equal_single_rank(tp):
     # reproduce the unsharded model (row-parallel sums are re-associated: 1e-4 of the logit range).
     shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
                  rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
-    seq_len = 384
+    seq_len = 576
     rng = np.random.default_rng(5)
     toks = rng.integers(0, 700, 10).astype(np.int32)
     one = host.Model(seq_len=seq_len, group_size=GS, **shape)
@@ -429,7 +429,7 @@ def test_tensor_parallel_ranks_equal_single_rank(tp):
             np.testing.assert_allclose(v, vf[:, r * kvl:(r + 1) * kvl], rtol=0, atol=1e-4 * np.abs(vf).max())
     # batched prompt pass under TP (GEMMs, flash attention on the local heads, reduces of whole
     # row blocks), long enough for the two-pass GEMM, then eager greedy steps
-    prompt = rng.integers(0, 700, 340).astype(np.int32)
+    prompt = rng.integers(0, 700, 530).astype(np.int32)
     ref_last = one.prefill(prompt)
     one.decode(6, use_graph=False)
     ref_hist = one.history(len(prompt) + 7)
