@@ -106,28 +106,22 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
   // later loads are still in flight
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int col = (c0 + u) * 1024 + col_lane;
+    // Columns past M re-read the row's last 16 weights: x is staged as zero there, so the products
+    // vanish.  Unconditional loads matter: under a per-lane column test the compiler branches
+    // around every load and waits for the whole batch before the first product.
+    const int col = min((c0 + u) * 1024 + col_lane, a.M - 16);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = rows[r];
-      if (col < a.M) {
-        const size_t off = (size_t)row * (size_t)a.M + (size_t)col;
-        wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
-        sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
-                                              (col >> a.gs_shift));
-        if constexpr (GU) {
-          const size_t off2 = off + (size_t)a.swiglu_half * (size_t)a.M;
-          wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
-          sc2[r][u] = __builtin_nontemporal_load(
-              a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
-        }
-      } else {
-        wv[r][u] = i32x4{0, 0, 0, 0};
-        sc[r][u] = 0.f;
-        if constexpr (GU) {
-          wv2[r][u] = i32x4{0, 0, 0, 0};
-          sc2[r][u] = 0.f;
-        }
+      const size_t off = (size_t)row * (size_t)a.M + (size_t)col;
+      wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
+      sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
+                                            (col >> a.gs_shift));
+      if constexpr (GU) {
+        const size_t off2 = off + (size_t)a.swiglu_half * (size_t)a.M;
+        wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
+        sc2[r][u] = __builtin_nontemporal_load(
+            a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
       }
     }
   }
