@@ -131,39 +131,57 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
 // weight g the staged vector is g*x and the function returns rsqrt(mean(x^2)+eps), which the
 // caller applies to the finished row sums: norm_w * (rs * x) of cpu/rmsnorm_kernel.cpp:30-32 with
 // the scalar factored out of the dot product.  Ends with one workgroup barrier.
-__device__ __forceinline__ float stage_x(const GemvW8Args& a, f32x4* xs, float* red) {
+template <bool NORM>
+__device__ __forceinline__ float stage_x_impl(const GemvW8Args& a, f32x4* xs, float* red) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nwaves = blockDim.x >> 6;
+  const int nwaves = blockDim.x >> 6, bd = blockDim.x;
   const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
   const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w);
   const int n4 = a.chunks * 256;
   const int m4 = a.M >> 2;
   float ss = 0.f;
-  for (int i = tid; i < n4; i += blockDim.x) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < m4) {
-      v = xg[i];
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      if (ng) {
-        const f32x4 g = ng[i];
-        v = f32x4{g.x * v.x, g.y * v.y, g.z * v.z, g.w * v.w};
+  // Four loads per thread are requested before the first is used (unconditional, index clamped:
+  // a load under a test would be waited for one at a time).
+  constexpr int PER = 4;
+  for (int i0 = tid; i0 < n4; i0 += PER * bd) {
+    f32x4 v[PER], g[NORM ? PER : 1];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int idx = min(i0 + j * bd, m4 - 1);
+      v[j] = xg[idx];
+      if constexpr (NORM) g[j] = ng[idx];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = i0 + j * bd;
+      if (i < n4) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (i < m4) {
+          o = v[j];
+          ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+          if constexpr (NORM) o = f32x4{g[j].x * o.x, g[j].y * o.y, g[j].z * o.z, g[j].w * o.w};
+        }
+        const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
+        xs[((c * 4 + p) << 6) + l] = o;
       }
     }
-    const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
-    xs[((c * 4 + p) << 6) + l] = v;
   }
   float rs = 1.0f;
-  if (ng) {
+  if constexpr (NORM) {
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
   }
   __syncthreads();
-  if (ng) {
+  if constexpr (NORM) {
     float tot = 0.f;
     for (int w = 0; w < nwaves; ++w) tot += red[w];
     rs = 1.0f / sqrtf(tot / (float)a.M + a.norm_eps);
   }
   return rs;
+}
+
+__device__ __forceinline__ float stage_x(const GemvW8Args& a, f32x4* xs, float* red) {
+  return a.norm_w ? stage_x_impl<true>(a, xs, red) : stage_x_impl<false>(a, xs, red);
 }
 
 // One batch of weights in registers: R rows x U chunks (and the paired "up" rows for gate/up).
