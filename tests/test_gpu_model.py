@@ -395,13 +395,20 @@ def _run_ranks(models, fn):
     return out
 
 
-@pytest.mark.parametrize("tp", [2, 4])
-def test_tensor_parallel_ranks_equal_single_rank(tp):
+TP_SMALL = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
+                rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+# one Llama-3-8B layer: at tp = 8 every rank holds exactly the per-GPU shapes of the 8-GPU
+# benchmark run (QKV 768 x 4096, Wo 4096 x 512, W1|W3 3584 x 4096, W2 4096 x 1792, one kv head)
+TP_8B_LAYER = dict(dim=4096, hidden_dim=14336, layer_num=1, head_num=32, kv_head_num=8,
+                   vocab_size=700, rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+
+
+@pytest.mark.parametrize("tp,shape", [(2, TP_SMALL), (4, TP_SMALL), (8, TP_8B_LAYER)],
+                         ids=["tp2", "tp4", "tp8-8b-layer"])
+def test_tensor_parallel_ranks_equal_single_rank(tp, shape):
     # Every rank of a TP model as an object of this process, the all-reduces through a host
     # rendezvous: column/row shards, the residual owner and the two reduces per layer must
     # reproduce the unsharded model (row-parallel sums are re-associated: 1e-4 of the logit range).
-    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
-                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
     seq_len = 576
     rng = np.random.default_rng(5)
     toks = rng.integers(0, 700, 10).astype(np.int32)
@@ -421,7 +428,7 @@ def test_tensor_parallel_ranks_equal_single_rank(tp):
     assert np.abs(got[0] - want).max() <= 1e-4 * np.abs(want).max()
     # each rank's cache rows are its kv heads' columns of the unsharded cache
     kvl = ranks[0].kv_dim_local
-    for layer in range(2):
+    for layer in range(shape["layer_num"]):
         kf, vf = one.read_kv(layer, len(toks))
         for r, m in enumerate(ranks):
             k, v = m.read_kv(layer, len(toks))
