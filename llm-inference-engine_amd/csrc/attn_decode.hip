@@ -120,19 +120,21 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
 
   const int t_begin = split * tiles_per_split;
   const int t_end = min(t_begin + tiles_per_split, ntiles);
+  // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e].  Lanes past the last
+  // head of the group repeat it (their output columns are never stored): the loads stay
+  // unconditional (a load under a lane test is branched around and waited for on its own) and go
+  // out ahead of the tile loads: they hit in L2 and loads return in order.
+  float qf[NJ][4];
+  const float* qrow = q + ((size_t)kvh * kv_mul + min(n, kv_mul - 1)) * HS + 4 * g;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + 16 * j);
+    qf[j][0] = v.x; qf[j][1] = v.y; qf[j][2] = v.z; qf[j][3] = v.w;
+  }
+
   int t = t_begin + wave;
   AttnTile<HS> cur;
   if (t < t_end) attn_load_tile<HS, KVT>(cur, kbase, vbase, t << 4, last, kv_dim, n, g);
-
-  // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e]
-  float qf[NJ][4];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < kv_mul)
-      v = *reinterpret_cast<const f32x4*>(q + ((size_t)kvh * kv_mul + n) * HS + 16 * j + 4 * g);
-    qf[j][0] = v.x; qf[j][1] = v.y; qf[j][2] = v.z; qf[j][3] = v.w;
-  }
 
   f32x4 o[NH][4];
 #pragma unroll
@@ -288,14 +290,13 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
         float M = -INFINITY;
 #pragma unroll
         for (int c = 0; c < kMaxSplits / 64; ++c) {
+          // unconditional (clamped) loads: a load under a lane test is branched around and
+          // waited for on its own, one memory round trip per round
           const int sp = c * 64 + lane;
-          m[c] = -INFINITY;
-          l[c] = 0.f;
-          if (sp < nsplit) {
-            const float2 ml = *reinterpret_cast<const float2*>(base + (size_t)sp * stride + HS);
-            m[c] = ml.x;
-            l[c] = ml.y;
-          }
+          const float2 ml =
+              *reinterpret_cast<const float2*>(base + (size_t)min(sp, nsplit - 1) * stride + HS);
+          m[c] = sp < nsplit ? ml.x : -INFINITY;
+          l[c] = sp < nsplit ? ml.y : 0.f;
           M = fmaxf(M, m[c]);
         }
         M = wave_max(M);
