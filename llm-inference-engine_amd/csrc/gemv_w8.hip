@@ -127,39 +127,53 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
   }
 }
 
-// Stages x in LDS: slot (c*4+p)*64+l <- x[c*1024 + l*16 + p*4 .. +4), zero past M.  With a norm
-// weight g the staged vector is g*x and the function returns rsqrt(mean(x^2)+eps), which the
+// Staging of x in LDS: slot (c*4+p)*64+l <- x[c*1024 + l*16 + p*4 .. +4), zero past M.  With a
+// norm weight g the staged vector is g*x and commit_x returns rsqrt(mean(x^2)+eps), which the
 // caller applies to the finished row sums: norm_w * (rs * x) of cpu/rmsnorm_kernel.cpp:30-32 with
-// the scalar factored out of the dot product.  Ends with one workgroup barrier.
-template <bool NORM>
-__device__ __forceinline__ float stage_x_impl(const GemvW8Args& a, f32x4* xs, float* red) {
+// the scalar factored out of the dot product.
+//
+// Two steps, because loads return in order: request_x asks for a thread's first four vectors
+// BEFORE the first weight batch is requested, commit_x (after it) waits for them only -- the
+// weights stay in flight across the LDS writes, the barrier and the norm reduction.  Requested
+// behind the weights, x could not be touched before every weight of the batch had arrived.
+constexpr int kXPer = 4;  // loads per thread and pass, all requested before the first is used
+struct GemvXRegs {
+  f32x4 v[kXPer];
+  f32x4 g[kXPer];
+};
+
+// Unconditional loads with a clamped index: a load under a test would be waited for on its own.
+__device__ __forceinline__ void request_x(const GemvW8Args& a, int i0, GemvXRegs& X) {
+  const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
+  const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
+  const int m4 = a.M >> 2, bd = blockDim.x;
+#pragma unroll
+  for (int j = 0; j < kXPer; ++j) {
+    const int idx = min(i0 + j * bd, m4 - 1);
+    X.v[j] = xg[idx];
+    if (a.norm_w) X.g[j] = ng[idx];
+  }
+}
+
+// Ends with one workgroup barrier.
+__device__ __forceinline__ float commit_x(const GemvW8Args& a, f32x4* xs, float* red, GemvXRegs& X) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwaves = blockDim.x >> 6, bd = blockDim.x;
-  const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
-  const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w);
   const int n4 = a.chunks * 256;
   const int m4 = a.M >> 2;
+  const bool norm = a.norm_w != nullptr;
   float ss = 0.f;
-  // Four loads per thread are requested before the first is used (unconditional, index clamped:
-  // a load under a test would be waited for one at a time).
-  constexpr int PER = 4;
-  for (int i0 = tid; i0 < n4; i0 += PER * bd) {
-    f32x4 v[PER], g[NORM ? PER : 1];
+  for (int i0 = tid; i0 < n4; i0 += kXPer * bd) {
+    if (i0 != tid) request_x(a, i0, X);  // the first pass was requested ahead of the weights
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int idx = min(i0 + j * bd, m4 - 1);
-      v[j] = xg[idx];
-      if constexpr (NORM) g[j] = ng[idx];
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
+    for (int j = 0; j < kXPer; ++j) {
       const int i = i0 + j * bd;
       if (i < n4) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         if (i < m4) {
-          o = v[j];
+          o = X.v[j];
           ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-          if constexpr (NORM) o = f32x4{g[j].x * o.x, g[j].y * o.y, g[j].z * o.z, g[j].w * o.w};
+          if (norm) o = f32x4{X.g[j].x * o.x, X.g[j].y * o.y, X.g[j].z * o.z, X.g[j].w * o.w};
         }
         const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
         xs[((c * 4 + p) << 6) + l] = o;
@@ -167,21 +181,17 @@ __device__ __forceinline__ float stage_x_impl(const GemvW8Args& a, f32x4* xs, fl
     }
   }
   float rs = 1.0f;
-  if constexpr (NORM) {
+  if (norm) {
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
   }
   __syncthreads();
-  if constexpr (NORM) {
+  if (norm) {
     float tot = 0.f;
     for (int w = 0; w < nwaves; ++w) tot += red[w];
     rs = 1.0f / sqrtf(tot / (float)a.M + a.norm_eps);
   }
   return rs;
-}
-
-__device__ __forceinline__ float stage_x(const GemvW8Args& a, f32x4* xs, float* red) {
-  return a.norm_w ? stage_x_impl<true>(a, xs, red) : stage_x_impl<false>(a, xs, red);
 }
 
 // One batch of weights in registers: R rows x U chunks (and the paired "up" rows for gate/up).
@@ -198,25 +208,36 @@ template <int R, bool GU>
 struct GemvRows {
   float total[R];
   float total2[GU ? R : 1];
-  float addend[R];                     // bias + residual
+  float bias[R];                       // 0 without a bias vector
+  float residual[R];                   // 0 without a residual vector
   float rope_s[R / 2 > 0 ? R / 2 : 1];  // sin / cos of each rotation pair
   float rope_c[R / 2 > 0 ? R / 2 : 1];
 };
 
-// Clears the totals and requests the epilogue operands now, not after the reduction, so no
-// dependent load is left for the tail.
 template <int R, int MODE>
-__device__ __forceinline__ void begin_rows(const GemvW8Args& a, int r0, int row_end, int pos,
-                                           GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+__device__ __forceinline__ void begin_rows(GemvRows<R, MODE == GEMV_GATE_UP>& S) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     S.total[r] = 0.f;
     if constexpr (MODE == GEMV_GATE_UP) S.total2[r] = 0.f;
+  }
+}
+
+// Requests the epilogue operands of a row set ahead of its weights, so no dependent load is left
+// for the tail.  The values are only assigned here, never used: a use under the pointer test would
+// put a full wait inside the branch, one memory round trip per operand before the first weight is
+// requested.  (Requesting them behind the last weight batch instead measured the same on the
+// token loop and 3-6 % slower on the large plain shapes.)
+template <int R, int MODE>
+__device__ __forceinline__ void request_epilogue(const GemvW8Args& a, int r0, int row_end, int pos,
+                                                 GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
     const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
-    S.addend[r] = 0.f;
-    if (a.bias) S.addend[r] += a.bias[row];
+    float b = 0.f, res = 0.f;
+    if (a.bias) b = a.bias[row];
     if constexpr (MODE != GEMV_QKV_ROPE) {
-      if (a.residual) S.addend[r] += a.residual[row];
+      if (a.residual) res = a.residual[row];
     } else if ((r & 1) == 0) {
       // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
       const int in_head = row % a.head_size;
@@ -224,6 +245,8 @@ __device__ __forceinline__ void begin_rows(const GemvW8Args& a, int r0, int row_
       S.rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
       S.rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];
     }
+    S.bias[r] = b;
+    S.residual[r] = res;
   }
 }
 
@@ -271,7 +294,7 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
       const int v = r0 + r;
       if (v < row_end) {  // row counts are even, so v+1 is valid too
         const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
-        float o0 = S.total[r] + S.addend[r], o1 = S.total[r + 1] + S.addend[r + 1];
+        float o0 = S.total[r] + S.bias[r], o1 = S.total[r + 1] + S.bias[r + 1];
         if (v < a.k1) {
           const float fci = S.rope_s[r / 2], fcr = S.rope_c[r / 2];
           const float t0 = o0 * fcr - o1 * fci;
@@ -291,7 +314,7 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
         float* dst;
         int rr;
         route(a, row, 0, dst, rr);
-        dst[rr] = S.total[r] + S.addend[r];
+        dst[rr] = S.total[r] + (S.bias[r] + S.residual[r]);
       }
     }
   }
@@ -314,11 +337,13 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
   const int col_lane = lane * 16;
   const int r_first = row_begin + wave * R;
 
-  // A wave without rows only helps staging x.  The others request their first batch of weights
-  // BEFORE staging (inside the loop below, first trip), so the HBM round trip of the weights
-  // overlaps the L2 round trip and the optional normalisation of x.
+  // A wave without rows only helps staging x.  The others request x, then their first batch of
+  // weights, and only then stage x (inside the loop below, first trip), so the HBM round trip of
+  // the weights overlaps the staging and the optional normalisation of x.
+  GemvXRegs X;
+  request_x(a, threadIdx.x, X);
   if (r_first >= row_end) {
-    stage_x(a, xs, red);
+    commit_x(a, xs, red, X);
     return;
   }
   bool staged = false;
@@ -329,12 +354,13 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
   GemvBatch<R, U, GU> B;
   GemvRows<R, GU> S;
   for (int r0 = r_first; r0 < row_end; r0 += nwaves * R) {
-    begin_rows<R, MODE>(a, r0, row_end, pos, S);
+    begin_rows<R, MODE>(S);
+    request_epilogue<R, MODE>(a, r0, row_end, pos, S);
     for (int c0 = 0; c0 < a.chunks; c0 += U) {
       load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2,
                                                     B.sc2);
       if (!staged) {
-        rs = stage_x(a, xs, red);
+        rs = commit_x(a, xs, red, X);
         staged = true;
       }
       consume<R, U, MODE>(a, xs, lane, c0, B, S);
