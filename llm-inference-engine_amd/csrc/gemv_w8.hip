@@ -346,22 +346,44 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
     commit_x(a, xs, red, X);
     return;
   }
-  bool staged = false;
   float rs = 1.0f;
   int pos = 0;
   if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
 
   GemvBatch<R, U, GU> B;
   GemvRows<R, GU> S;
-  for (int r0 = r_first; r0 < row_end; r0 += nwaves * R) {
+  // Narrow matrices (at most two chunks, the R = 4 / U = 2 forms): many row sets per wave, and the
+  // registers holding the requested x must not stay live across the loop over them (it costs
+  // a quarter of the rate on a 128256 x 2048 matrix), so the first row set is written out on its
+  // own.  Wide matrices: a single loop with a staged flag is the faster form (measured both ways).
+  constexpr bool kPeelFirst = GU ? U == 2 : R == 4;
+  int r0 = r_first;
+  if constexpr (kPeelFirst) {
+    begin_rows<R, MODE>(S);
+    request_epilogue<R, MODE>(a, r0, row_end, pos, S);
+    load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, 0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
+    rs = commit_x(a, xs, red, X);
+    consume<R, U, MODE>(a, xs, lane, 0, B, S);
+    for (int c0 = U; c0 < a.chunks; c0 += U) {
+      load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2,
+                                                    B.sc2);
+      consume<R, U, MODE>(a, xs, lane, c0, B, S);
+    }
+    finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
+    r0 += nwaves * R;
+  }
+  bool staged = kPeelFirst;
+  for (; r0 < row_end; r0 += nwaves * R) {
     begin_rows<R, MODE>(S);
     request_epilogue<R, MODE>(a, r0, row_end, pos, S);
     for (int c0 = 0; c0 < a.chunks; c0 += U) {
       load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2,
                                                     B.sc2);
-      if (!staged) {
-        rs = commit_x(a, xs, red, X);
-        staged = true;
+      if constexpr (!kPeelFirst) {
+        if (!staged) {
+          rs = commit_x(a, xs, red, X);
+          staged = true;
+        }
       }
       consume<R, U, MODE>(a, xs, lane, c0, B, S);
     }
