@@ -155,30 +155,41 @@ __device__ __forceinline__ void request_x(const GemvW8Args& a, int i0, GemvXRegs
   }
 }
 
-// Ends with one workgroup barrier.
+// One pass of staging: the kXPer vectors of X (requested for pass start i0) go to LDS; returns
+// their sum of squares.
+__device__ __forceinline__ float stage_pass(const GemvW8Args& a, f32x4* xs, int i0, bool norm,
+                                            const GemvXRegs& X) {
+  const int n4 = a.chunks * 256, m4 = a.M >> 2, bd = blockDim.x;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < kXPer; ++j) {
+    const int i = i0 + j * bd;
+    if (i < n4) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (i < m4) {
+        o = X.v[j];
+        ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+        if (norm) o = f32x4{X.g[j].x * o.x, X.g[j].y * o.y, X.g[j].z * o.z, X.g[j].w * o.w};
+      }
+      const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
+      xs[((c * 4 + p) << 6) + l] = o;
+    }
+  }
+  return ss;
+}
+
+// Ends with one workgroup barrier.  The first pass (requested ahead of the weights) is straight-
+// line code of its own: sharing a loop body with the later passes, whose loads are the youngest
+// in flight, it would inherit their wait and sit until the weights had arrived too.
 __device__ __forceinline__ float commit_x(const GemvW8Args& a, f32x4* xs, float* red, GemvXRegs& X) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwaves = blockDim.x >> 6, bd = blockDim.x;
   const int n4 = a.chunks * 256;
-  const int m4 = a.M >> 2;
   const bool norm = a.norm_w != nullptr;
-  float ss = 0.f;
-  for (int i0 = tid; i0 < n4; i0 += kXPer * bd) {
-    if (i0 != tid) request_x(a, i0, X);  // the first pass was requested ahead of the weights
-#pragma unroll
-    for (int j = 0; j < kXPer; ++j) {
-      const int i = i0 + j * bd;
-      if (i < n4) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (i < m4) {
-          o = X.v[j];
-          ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-          if (norm) o = f32x4{X.g[j].x * o.x, X.g[j].y * o.y, X.g[j].z * o.z, X.g[j].w * o.w};
-        }
-        const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
-        xs[((c * 4 + p) << 6) + l] = o;
-      }
-    }
+  float ss = stage_pass(a, xs, tid, norm, X);
+  for (int i0 = tid + kXPer * bd; i0 < n4; i0 += kXPer * bd) {
+    request_x(a, i0, X);
+    ss += stage_pass(a, xs, i0, norm, X);
   }
   float rs = 1.0f;
   if (norm) {
