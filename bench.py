@@ -202,6 +202,10 @@ def main():
 
     rng = np.random.default_rng(42)
     prompt = rng.integers(0, shape["vocab_size"], args.context).astype(np.int32)
+    if args.context > 0:
+        # untimed first pass: one-off costs (lazy code-object loading, raising LDS limits, growing
+        # the prompt scratch) stay out of the prefill figure; the timed pass rewrites the same rows
+        model.prefill(prompt)
     fence()
     t0 = time.perf_counter()
     if args.context > 0:
