@@ -32,11 +32,21 @@ constexpr size_t kTicketBytes = kTicketStride * kMaxTickets;
 // workspace record per (head, split): O[hs], then m, l and two pad words (16-byte aligned rows)
 __host__ __device__ inline size_t attn_ws_stride(int hs) { return (size_t)hs + 4; }
 
-// split geometry shared by host and device: whole groups of kAttnWaves tiles per split, so every
-// wave of a workgroup gets the same number of 16-key tiles
-__host__ __device__ inline int attn_tiles_per_split(int ntiles, int grid_splits) {
-  const int tps = (ntiles + grid_splits - 1) / grid_splits;
-  return (tps + kAttnWaves - 1) / kAttnWaves * kAttnWaves;
+// Split geometry shared by host and device.  The ntiles 16-key tiles of a kv head are cut into
+// nsplit contiguous runs whose lengths differ by at most one (the first `rem` runs hold one tile
+// more); never more splits than ceil(ntiles / kAttnWaves), so no wave of a split is idle unless
+// the whole context is shorter than that.
+struct AttnSplit {
+  int nsplit, base, rem;
+  __host__ __device__ int begin(int split) const { return split * base + (split < rem ? split : rem); }
+  __host__ __device__ int count(int split) const { return base + (split < rem ? 1 : 0); }
+  __host__ __device__ int longest() const { return base + (rem > 0 ? 1 : 0); }
+};
+__host__ __device__ inline AttnSplit attn_split(int ntiles, int grid_splits) {
+  int ns = (ntiles + kAttnWaves - 1) / kAttnWaves;
+  if (ns > grid_splits) ns = grid_splits;
+  if (ns < 1) ns = 1;
+  return AttnSplit{ns, ntiles / ns, ntiles % ns};
 }
 
 // e^x for x <= 0 (or -inf) on the hardware exponential: one v_exp_f32 instead of the library
@@ -112,14 +122,14 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   // the grid is then sized for the longest context and surplus splits leave at once.
   const int last = pos_dev ? *pos_dev : last_val;
   const int ntiles = (last >> 4) + 1;
-  const int tiles_per_split = attn_tiles_per_split(ntiles, (int)gridDim.y);
-  const int nsplit = (ntiles + tiles_per_split - 1) / tiles_per_split;
+  const AttnSplit cut = attn_split(ntiles, (int)gridDim.y);
+  const int nsplit = cut.nsplit;
   if (split >= nsplit) return;
   const KVT* kbase = kc + (size_t)kvh * HS;
   const KVT* vbase = vc + (size_t)kvh * HS;
 
-  const int t_begin = split * tiles_per_split;
-  const int t_end = min(t_begin + tiles_per_split, ntiles);
+  const int t_begin = cut.begin(split);
+  const int t_end = t_begin + cut.count(split);
   // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e].  Lanes past the last
   // head of the group repeat it (their output columns are never stored): the loads stay
   // unconditional (a load under a lane test is branched around and waited for on its own) and go
@@ -422,9 +432,13 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // `pos` sizes the grid: the actual position when passed by value, the largest position the
   // launch may ever see when it is read from pos_dev.
   const int ntiles = (pos >> 4) + 1;
-  // one tile per wave is the finest useful cut; keep the grid near 4 workgroups per CU
+  // One tile per wave is the finest useful cut.  Beyond two workgroups per CU the splits stop
+  // growing in number and grow in length instead (runs of 4..8 tiles: some waves take two tiles,
+  // both requested up front by the PREFETCH form): a CU that draws a third workgroup finishes
+  // late, and so does a kv head whose split count runs into a third merge pass -- 69 splits of 4
+  // tiles cost 15.3 us at 4368 keys where 64 splits of 4..5 cost 14.2.
   int nsplit = (ntiles + kAttnWaves - 1) / kAttnWaves;
-  const int cap_grid = (1024 + kvh - 1) / kvh;
+  const int cap_grid = 512 / kvh > 0 ? 512 / kvh : 1;
   if (nsplit > cap_grid) nsplit = cap_grid;
   if (nsplit > kMaxSplits) nsplit = kMaxSplits;
   if (kvh > kMaxTickets) return KX_EUNSUPPORTED;
@@ -434,13 +448,13 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
         workspace && workspace_bytes > kTicketBytes ? (workspace_bytes - kTicketBytes) / per_split : 0;
     if (fit < (size_t)nsplit) nsplit = fit < 1 ? 1 : (int)fit;
   }
-  const int tps = attn_tiles_per_split(ntiles, nsplit);
-  nsplit = (ntiles + tps - 1) / tps;  // no empty splits at `pos`; the kernel derives the same cut
+  const AttnSplit cut = attn_split(ntiles, nsplit);
+  nsplit = cut.nsplit;  // the kernel derives the same cut from the grid and the actual position
   unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
   float* ws = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes) : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(kvh, nsplit), block(kAttnWaves * 64);
-  const bool prefetch = tps > kAttnWaves;
+  const bool prefetch = cut.longest() > kAttnWaves;
 #define KX_ATTN_LAUNCH(HS_)                                                                      \
   do {                                                                                           \
     if (prefetch)                                                                                \
