@@ -488,7 +488,12 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
   // aim for ~4 workgroups per CU on big matrices, one pass on small ones
   const int target_blocks = 256 * 4;
   int rpb = (out_rows + target_blocks - 1) / target_blocks;
-  rpb = ((rpb + per_iter - 1) / per_iter) * per_iter;
+  // Every wave gets work (at least one row set per wave); beyond that only whole row sets, so the
+  // grid stays a multiple of the CU count where the row count allows it: 14336 gate/up pairs are
+  // 1024 blocks of 14 (waves take 4, 4, 3, 3), not 896 blocks of 16 that leave half of the CUs
+  // with a fourth block to finish.
+  if (rpb < per_iter) rpb = per_iter;
+  rpb = ((rpb + R - 1) / R) * R;
   a.rows_per_block = rpb;
   // (R, U) per mode from a sweep on MI355X: more loads per wave than these lowers occupancy and
   // loses; two register sets per wave (software pipelining) lost 30 % against plain occupancy
