@@ -216,6 +216,47 @@ def test_mha_decode_long_context_several_tiles_per_wave():
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("H,KVH,hs,S,pos", [
+    (32, 8, 128, 4700, 4096), (32, 8, 128, 4700, 4367), (32, 8, 128, 6200, 6143),
+    (12, 12, 64, 3100, 3000), (16, 4, 128, 8300, 8200)])
+def test_mha_decode_uneven_splits_past_two_workgroups_per_cu(H, KVH, hs, S, pos):
+    # once one tile per wave would need more than two workgroups per CU the splits stop growing in
+    # number: runs of near-equal length, the first `rem` one tile longer, some waves with two tiles
+    rng = np.random.default_rng(pos)
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_mha_decode_device_position_grid_for_a_longer_context():
+    # graph-replay form with the grid cut for 4736 rows (64 splits of 4..5 tiles at the end) and
+    # positions on both sides of the point where the first split gets its fifth tile
+    rng = np.random.default_rng(92)
+    H, KVH, hs, S = 32, 8, 128, 4736
+    kvd = KVH * hs
+    kc = rng.standard_normal((1, S, kvd)).astype(np.float32)
+    vc = rng.standard_normal((1, S, kvd)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    L = kx.lib()
+    dq, dk, dv = kx.Buf.from_numpy(q), kx.Buf.from_numpy(kc), kx.Buf.from_numpy(vc)
+    out = kx.Buf.zeros(H * hs)
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    pos_dev = kx.Buf.zeros(1, np.int32)
+    for pos in (4095, 4096, 4111, 3, 4367, 1000, 4623, 4735):
+        pos_dev.upload(np.array([pos], np.int32))
+        kx.check(L.kx_mha_decode_dpos_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H,
+                                          H // KVH, hs, kvd, S, 0, ws.ptr, wsb, None))
+        kx.sync()
+        want = kxo.mha(pos, H, 0, S, kvd, H // KVH, hs, q, kc, vc).reshape(H, hs)
+        np.testing.assert_allclose(out.numpy(np.float32, (H, hs)), want, rtol=0, atol=2e-5,
+                                   err_msg=f"pos={pos}")
+    assert not ws.numpy(np.uint8, (wsb,))[:16384].any()  # tickets are back at zero
+
+
 def test_mha_decode_device_position_one_workspace_many_launches():
     # the form used under graph replay: the grid is sized for the longest context, the position
     # is read from device memory, and every launch shares one workspace whose arrival counters
