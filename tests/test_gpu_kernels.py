@@ -42,6 +42,9 @@ def test_gemv_w8_golden(golden, name):
 @pytest.mark.parametrize("K,M", [(1, 64), (3, 64), (7, 192), (64, 1024), (130, 2048), (512, 2048),
                                  (33, 3584), (256, 4096), (17, 14336), (8, 18944), (5, 28672),
                                  (2048, 2048),
+                                 # rows per block that are not a whole round of waves (10 and 18
+                                 # rows over 4 waves of 2): the last waves run one row set fewer
+                                 (9000, 4096), (18000, 2048),
                                  # per-rank shapes of the tensor-parallel configs: 8B at TP=8
                                  # (Wo, W2), Qwen2.5-7B at TP=4 (Wo, W2), 70B at TP=8 (W2)
                                  (4096, 512), (4096, 1792), (3584, 896), (3584, 4736), (1024, 3584)])
@@ -94,7 +97,8 @@ def test_gemv_w8_ex_routing_bias_residual():
                   + 1e-6)
 
 
-@pytest.mark.parametrize("H,M", [(256, 512), (1000, 2048), (344, 4096), (1792, 4096), (4736, 3584)])
+@pytest.mark.parametrize("H,M", [(256, 512), (1000, 2048), (344, 4096), (1792, 4096), (4736, 3584),
+                                 (14336, 4096)])  # the last: 14 pairs per block, waves take 4, 4, 3, 3
 def test_gemv_w8_swiglu(H, M):
     rng = np.random.default_rng(H)
     x, w, s = rand_w8(rng, 2 * H, M)
