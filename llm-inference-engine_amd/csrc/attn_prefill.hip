@@ -506,6 +506,9 @@ static int flash_attention_run(const float* query, const void* key_cache_any,
     if (kv_mul % d == 0) hpb = d;
   int qsubs = hpb >= 4 ? 1 : 4 / hpb;
   if (hpb * qsubs < 4) qsubs = (4 + hpb - 1) / hpb;
+  // With enough query rows a workgroup takes twice the rows (8 waves): a staged K/V tile then
+  // feeds twice the MFMA work (182 vs 194 us on 32 heads x 4096 rows).
+  if (hpb * qsubs * 2 <= 8 && Tq >= 64 * qsubs * 2) qsubs *= 2;
   const int threads = 64 * hpb * qsubs;
   const size_t layer_off = (size_t)layer_idx * (size_t)seq_len * (size_t)kv_dim;
   FaArgs a{};
