@@ -100,9 +100,42 @@ __device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __res
   }
 }
 
+// ---- 4x4x1 form (head size 128, at most 4 query heads per kv head) --------------------------------
+// v_mfma_f32_16x16x4_f32 spends 16 head columns on kv_mul heads; with kv_mul = 4 three quarters of
+// its cycles are idle, and a 16-key tile costs its wave 64 such instructions on the critical path.
+// v_mfma_f32_4x4x1_16B_f32 is the same arithmetic (an fp32 fma chain per output) as 16 independent
+// 4 x 4 blocks: block b of lanes 4b..4b+3 multiplies a 4-vector (one value per lane: rows) by a
+// 4-vector (one value per lane: columns).  Scores: lane l = 16 qd + key holds K[key][16j + 4qd + e]
+// (rows = the 4 keys of its block) and Q[head l&3][same dims] (columns = heads); the four dim
+// quarters qd are summed across lanes afterwards.  Output: the probabilities of (key, head) go
+// through 64 floats of LDS per wave into "rows = heads", the V values are "columns = dims":
+// block b accumulates dims 4(l&31) + t for keys of parity l>>5, t = 0..3 in four accumulators.
+struct AttnTile4 {
+  f32x4 k[8];
+  f32x4 v[8];
+};
+
+template <typename KVT>
+__device__ __forceinline__ void attn_load_tile4(AttnTile4& T, const KVT* __restrict__ kbase,
+                                                const KVT* __restrict__ vbase, int key0, int last,
+                                                int kv_dim, int lane) {
+  const KVT* kr = kbase + (size_t)min(key0 + (lane & 15), last) * kv_dim + 4 * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) T.k[j] = load_kv4(kr + 16 * j);
+  const int hi = lane >> 5, c4 = (lane & 31) * 4;
+#pragma unroll
+  for (int st = 0; st < 8; ++st)
+    T.v[st] = load_kv4(vbase + (size_t)min(key0 + 2 * st + hi, last) * kv_dim + c4);
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 // PREFETCH: a wave with several tiles requests the next one before it consumes the current one
 // (costs a second set of tile registers; pointless when every wave has a single tile).
-template <int HS, bool PREFETCH, typename KVT>
+// M4: the 4x4x1 form above (HS = 128, kv_mul <= 4).
+template <int HS, bool PREFETCH, typename KVT, bool M4 = false>
 __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
@@ -111,9 +144,10 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   constexpr int NH = AttnTile<HS>::NH;  // 64-dim halves of the output
   __shared__ float sm_m[kAttnWaves][16];
   __shared__ float sm_l[kAttnWaves][16];
-  __shared__ float sm_o[kAttnWaves][16][HS];
+  __shared__ __attribute__((aligned(16))) float sm_o[kAttnWaves][16][HS];
   __shared__ float sm_sf[kAttnWaves * kMaxSplits];  // final merge: split weights, one set per wave
   __shared__ int sm_last;
+  __shared__ __attribute__((aligned(16))) float sm_p[M4 ? kAttnWaves * 64 : 4];  // M4: P of one tile per wave
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -130,6 +164,113 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
 
   const int t_begin = cut.begin(split);
   const int t_end = t_begin + cut.count(split);
+  if constexpr (M4) {
+    static_assert(!M4 || HS == 128, "the 4x4x1 form is laid out for 128-wide heads");
+    const int qd = lane >> 4, kb = (lane >> 2) & 3, hd = lane & 3, hi = lane >> 5;
+    // Q: lane (qd, *, head hd) holds Q[head][16j + 4qd + e]; requested ahead of the tile
+    f32x4 qf4[8];
+    const float* qrow = q + ((size_t)kvh * kv_mul + min(hd, kv_mul - 1)) * HS + 4 * qd;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf4[j] = *reinterpret_cast<const f32x4*>(qrow + 16 * j);
+
+    int t = t_begin + wave;
+    AttnTile4 cur;
+    if (t < t_end) attn_load_tile4<KVT>(cur, kbase, vbase, t << 4, last, kv_dim, lane);
+    // single-tile form: without the fences the scheduler sinks the tile loads into the product
+    // loop and waits for them one at a time (the prefetching form schedules better without)
+    if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
+    f32x4 o[4];  // o[t][r] = O[head r][dim 4(lane&31) + t], keys of parity hi
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    float* pl = sm_p + wave * 64;
+
+    for (; t < t_end; t += kAttnWaves) {
+      const int key0 = t << 4;
+      AttnTile4 nxt;
+      const bool more = t + kAttnWaves < t_end;
+      if (PREFETCH && more)
+        attn_load_tile4<KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane);
+      // ---- scores: rows = keys 4kb..4kb+3, columns = heads, this lane's quarter of the dims ----
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s0 = mfma4(cur.k[j].x, qf4[j].x, s0);
+        s1 = mfma4(cur.k[j].y, qf4[j].y, s1);
+        s0 = mfma4(cur.k[j].z, qf4[j].z, s0);
+        s1 = mfma4(cur.k[j].w, qf4[j].w, s1);
+      }
+      float sv[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // sum of the four dim quarters
+        sv[r] += lane_xor16(sv[r]);
+        sv[r] += lane_xor32(sv[r]);
+        sv[r] *= scale;
+        if (key0 + 4 * kb + r > last) sv[r] = -INFINITY;
+      }
+      // every lane (any qd, kb) of head hd ends up with the head's maximum over the 16 keys
+      float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+      mx = fmaxf(mx, dpp_mov<0x124>(mx));  // row_ror:4 -> the next key block, same head
+      mx = fmaxf(mx, dpp_mov<0x128>(mx));  // row_ror:8
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp(m_run - m_new);  // first tile: exp(-inf) = 0
+      m_run = m_new;
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pv[r] = fast_exp(sv[r] - m_new);
+      l_run = l_run * alpha + ((pv[0] + pv[1]) + (pv[2] + pv[3]));  // this lane's 4 keys
+      // P[key][head] -> LDS as [parity][head][step], key = 2 step + parity, so that a lane of
+      // the second product reads the 8 probabilities it needs as two 16-byte words
+      if (qd == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[((r & 1) * 4 + hd) * 8 + 2 * kb + (r >> 1)] = pv[r];
+      }
+      // the accumulators keep the head on the register axis: alpha of head r for every lane
+      const float ah[4] = {dpp_mov<0x00>(alpha), dpp_mov<0x55>(alpha), dpp_mov<0xAA>(alpha),
+                           dpp_mov<0xFF>(alpha)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e].x *= ah[0]; o[e].y *= ah[1]; o[e].z *= ah[2]; o[e].w *= ah[3];
+      }
+      const f32x4 pa0 = *reinterpret_cast<const f32x4*>(pl + (hi * 4 + hd) * 8);
+      const f32x4 pa1 = *reinterpret_cast<const f32x4*>(pl + (hi * 4 + hd) * 8 + 4);
+      const float pa[8] = {pa0.x, pa0.y, pa0.z, pa0.w, pa1.x, pa1.y, pa1.z, pa1.w};
+      // ---- output: rows = heads, columns = dims 4(lane&31) + t, one key per step ----
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        o[0] = mfma4(pa[st], cur.v[st].x, o[0]);
+        o[1] = mfma4(pa[st], cur.v[st].y, o[1]);
+        o[2] = mfma4(pa[st], cur.v[st].z, o[2]);
+        o[3] = mfma4(pa[st], cur.v[st].w, o[3]);
+      }
+      if (more) {
+        if (PREFETCH) cur = nxt;
+        else attn_load_tile4<KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane);
+      }
+      if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- wave result -> LDS ----
+    l_run += dpp_mov<0x124>(l_run);  // the four key blocks of a head
+    l_run += dpp_mov<0x128>(l_run);
+    if (lane < 4 && lane < kv_mul) {
+      sm_m[wave][lane] = m_run;
+      sm_l[wave][lane] = l_run;
+    }
+    float oo[4][4];  // [head r][t], both key parities
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      oo[0][e] = o[e].x + lane_xor32(o[e].x);
+      oo[1][e] = o[e].y + lane_xor32(o[e].y);
+      oo[2][e] = o[e].z + lane_xor32(o[e].z);
+      oo[3][e] = o[e].w + lane_xor32(o[e].w);
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < kv_mul)
+          *reinterpret_cast<f32x4*>(&sm_o[wave][r][4 * lane]) = f32x4{oo[r][0], oo[r][1], oo[r][2], oo[r][3]};
+    }
+  } else {
   // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e].  Lanes past the last
   // head of the group repeat it (their output columns are never stored): the loads stay
   // unconditional (a load under a lane test is branched around and waited for on its own) and go
@@ -229,6 +370,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
           if (d < HS) sm_o[wave][n][d] = vals[r];
         }
       }
+  }
   }
   __syncthreads();
 
@@ -455,19 +597,25 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(kvh, nsplit), block(kAttnWaves * 64);
   const bool prefetch = cut.longest() > kAttnWaves;
-#define KX_ATTN_LAUNCH(HS_)                                                                      \
+#define KX_ATTN_LAUNCH(HS_, M4_)                                                                 \
   do {                                                                                           \
     if (prefetch)                                                                                \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT>), grid, block, 0, s, query, kc, vc, out, \
-                         ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                      \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                 \
     else                                                                                         \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT>), grid, block, 0, s, query, kc, vc,     \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
                          out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale);                 \
   } while (0)
+  // up to four query heads per kv head: the 4x4x1 form of the matrix instruction (a quarter of
+  // the matrix-core cycles of the 16-column form, which leaves 12 head columns idle)
+  const bool m4 = head_size == 128 && kv_mul <= 4;
   switch (head_size) {
-    case 32: KX_ATTN_LAUNCH(32); break;
-    case 64: KX_ATTN_LAUNCH(64); break;
-    case 128: KX_ATTN_LAUNCH(128); break;
+    case 32: KX_ATTN_LAUNCH(32, false); break;
+    case 64: KX_ATTN_LAUNCH(64, false); break;
+    case 128:
+      if (m4) KX_ATTN_LAUNCH(128, true);
+      else KX_ATTN_LAUNCH(128, false);
+      break;
     default: return KX_EUNSUPPORTED;
   }
 #undef KX_ATTN_LAUNCH
