@@ -222,7 +222,11 @@ def test_mha_decode_long_context_several_tiles_per_wave():
 
 @pytest.mark.parametrize("H,KVH,hs,S,pos", [
     (32, 8, 128, 4700, 4096), (32, 8, 128, 4700, 4367), (32, 8, 128, 6200, 6143),
-    (12, 12, 64, 3100, 3000), (16, 4, 128, 8300, 8200)])
+    (12, 12, 64, 3100, 3000), (16, 4, 128, 8300, 8200),
+    # 128-wide heads with 1..4 query heads per kv head (the 4x4x1 matrix-instruction form): one kv
+    # head as on a rank of an 8-way split, several tiles per wave, fewer than four heads
+    (4, 1, 128, 4700, 4367), (4, 1, 128, 9100, 9000), (6, 2, 128, 2100, 2047), (2, 2, 128, 300, 257),
+    (3, 1, 128, 40, 33)])
 def test_mha_decode_uneven_splits_past_two_workgroups_per_cu(H, KVH, hs, S, pos):
     # once one tile per wave would need more than two workgroups per CU the splits stop growing in
     # number: runs of near-equal length, the first `rem` one tile longer, some waves with two tiles
