@@ -385,12 +385,19 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
     r0 += nwaves * R;
   }
   bool staged = kPeelFirst;
+  // The rotary sin/cos come from a table row that is new every token (an HBM miss behind a
+  // dependent load of the position): requested in front of the weights they would be waited for
+  // first, so that form asks for them behind the row set's last weight batch.
+  constexpr bool kEpilogueLate = MODE == GEMV_QKV_ROPE;
   for (; r0 < row_end; r0 += nwaves * R) {
     begin_rows<R, MODE>(S);
-    request_epilogue<R, MODE>(a, r0, row_end, pos, S);
+    if constexpr (!kEpilogueLate) request_epilogue<R, MODE>(a, r0, row_end, pos, S);
     for (int c0 = 0; c0 < a.chunks; c0 += U) {
       load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2,
                                                     B.sc2);
+      if constexpr (kEpilogueLate) {
+        if (c0 + U >= a.chunks) request_epilogue<R, MODE>(a, r0, row_end, pos, S);
+      }
       if constexpr (!kPeelFirst) {
         if (!staged) {
           rs = commit_x(a, xs, red, X);
