@@ -46,8 +46,10 @@ struct AttnSplit {
 // workgroups per CU) that is the cut; past it the splits grow longer AND fall back to one
 // workgroup per CU: with waves walking several tiles anyway, 256 workgroups of 8+ tiles beat 512 of
 // 4..5 (equal at 4.4k keys, 1.5 % of a token at 8k).
-__host__ __device__ inline AttnSplit attn_split(int ntiles, int grid_splits, int kvh) {
+// (fp32 cache only: with 16-bit rows a tile is half the bytes and the finer cut stays ahead.)
+__host__ __device__ inline AttnSplit attn_split(int ntiles, int grid_splits, int kvh, bool fp32_cache) {
   int ns = (ntiles + kAttnWaves - 1) / kAttnWaves;
+  if (ns > grid_splits && !fp32_cache) ns = grid_splits;
   if (ns > grid_splits) {
     const int one_per_cu = 256 / kvh > 0 ? 256 / kvh : 1;
     ns = grid_splits < one_per_cu ? grid_splits : one_per_cu;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   // the grid is then sized for the longest context and surplus splits leave at once.
   const int last = pos_dev ? *pos_dev : last_val;
   const int ntiles = (last >> 4) + 1;
-  const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x);
+  const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x, sizeof(KVT) == 4);
   const int nsplit = cut.nsplit;
   if (split >= nsplit) return;
   const KVT* kbase = kc + (size_t)kvh * HS;
@@ -600,7 +602,7 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // The grid keeps the two-per-CU split count even where the cut at `pos` falls back to one per CU:
   // a launch that reads its position from the device may see shorter contexts, for which the
   // finer cut is the better one (surplus workgroups leave at once).
-  const AttnSplit cut = attn_split(ntiles, nsplit, kvh);
+  const AttnSplit cut = attn_split(ntiles, nsplit, kvh, kFp32Cache);
   if (!pos_dev) nsplit = cut.nsplit;
   unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
   float* ws = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes) : nullptr;
