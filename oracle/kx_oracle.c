@@ -6,7 +6,9 @@
  * Parity pin: checked by tests/test_oracle_golden.py against (a) the known-answer
  * vectors of the reference's own tests (test/test_op/test_cu_matmul.cpp:10-106,
  * test/test_op/test_load.cpp:97-105) and (b) fixtures under tests/golden/ produced
- * by importing the reference's tools/model.py and tools/export_llama.py.
+ * by importing the reference's tools/model.py and tools/export_llama.py, and (c) the half-split
+ * RoPE / GQA / bias fixtures g6, g7 produced by sending Hugging Face models through the
+ * reference's tools/export_llama3.py and tools/export_qwen2.py (tests/golden/make_golden_hf.py).
  */
 #include "kx_oracle.h"
 
@@ -326,6 +328,10 @@ void kxo_forward_token(const kxo_weights* w, kxo_state* st, int32_t token, int32
     linear(c, w->wq_f, w->wq_q, w->wq_s, l, dim, dim, st->rms, st->q, threads);
     linear(c, w->wk_f, w->wk_q, w->wk_s, l, kvd, dim, st->rms, krow, threads);
     linear(c, w->wv_f, w->wv_q, w->wv_s, l, kvd, dim, st->rms, vrow, threads);
+    /* bias after the matmul, before RoPE (matmul.cpp:76-79; qwen2.cpp attention_qkv) */
+    if (w->bq) kxo_add(st->q, w->bq + (size_t)l * dim, st->q, dim);
+    if (w->bk) kxo_add(krow, w->bk + (size_t)l * kvd, krow, kvd);
+    if (w->bv) kxo_add(vrow, w->bv + (size_t)l * kvd, vrow, kvd);
     kxo_rope(c->rope_variant, dim, kvd, st->head_size, st->q, krow, pos, st->sin_cache,
              st->cos_cache);
     /* attention_mha :716-743 */
@@ -383,6 +389,49 @@ int kxo_parse_legacy_f32(const void* blob, size_t bytes, kxo_weights* out) {
   out->cls_f = shared ? out->emb : p;
   if (!shared) p += V * dim;
   if ((size_t)((const char*)p - (const char*)blob) > bytes) return -2;
+  return 0;
+}
+
+int kxo_parse_qwen2_f32(const void* blob, size_t bytes, kxo_weights* out) {
+  memset(out, 0, sizeof(*out));
+  if (bytes < 28) return -1;
+  int shared = 0;
+  kxo_config* c = &out->cfg;
+  if (read_header((const int32_t*)blob, c, &shared)) return -1;
+  c->group_size = 0;
+  size_t dim = c->dim, hid = c->hidden_dim, L = c->layer_num, V = c->vocab_size;
+  size_t hs = dim / c->head_num, kvd = hs * c->kv_head_num;
+  const float* p = (const float*)((const char*)blob + 28);
+  const float* end = (const float*)((const char*)blob + bytes);
+  /* order: tools/export_qwen2.py:96-130; offsets mirrored at qwen2.cpp:298-385 */
+  out->emb = p;            p += V * dim;
+  out->attn_norm = p;      p += L * dim;
+  size_t rows[3] = {dim, kvd, kvd};
+  float* wdst[3];
+  float* bdst[3];
+  for (int m = 0; m < 3; ++m) {
+    wdst[m] = (float*)malloc(L * rows[m] * dim * sizeof(float));
+    bdst[m] = (float*)malloc(L * rows[m] * sizeof(float));
+    for (size_t l = 0; l < L; ++l) {
+      if (p + rows[m] * dim + rows[m] > end) return -2;
+      memcpy(wdst[m] + l * rows[m] * dim, p, rows[m] * dim * sizeof(float));
+      p += rows[m] * dim;
+      memcpy(bdst[m] + l * rows[m], p, rows[m] * sizeof(float));
+      p += rows[m];
+    }
+  }
+  out->wq_f = wdst[0]; out->wk_f = wdst[1]; out->wv_f = wdst[2];
+  out->bq = bdst[0];   out->bk = bdst[1];   out->bv = bdst[2];
+  out->wo_f = p;           p += L * dim * dim;
+  out->ffn_norm = p;       p += L * dim;
+  out->w1_f = p;           p += L * hid * dim;
+  out->w2_f = p;           p += L * dim * hid;
+  out->w3_f = p;           p += L * hid * dim;
+  out->final_norm = p;     p += dim;
+  p += (size_t)c->seq_len * hs; /* freqs_cos + freqs_sin, skipped: qwen2.cpp:373-374 */
+  out->cls_f = shared ? out->emb : p;
+  if (!shared) p += V * dim;
+  if (p > end) return -2;
   return 0;
 }
 

@@ -99,6 +99,10 @@ typedef struct {
   const float* attn_norm; /* [L][dim] */
   const float* ffn_norm;  /* [L][dim] */
   const float* final_norm;
+  /* optional q/k/v biases, [L][dim] / [L][kv_dim] / [L][kv_dim]; NULL = none.  Added to the
+   * matmul output as MatmulLayer does (kuiper/source/op/matmul.cpp:76-79); the Qwen2 fp32 files
+   * carry them (kuiper/source/model/qwen2.cpp:306-333, tools/export_qwen2.py:102-110). */
+  const float *bq, *bk, *bv;
 } kxo_weights;
 
 typedef struct kxo_state kxo_state;
@@ -119,6 +123,10 @@ void kxo_forward_token(const kxo_weights* w, kxo_state* st, int32_t token, int32
  * :134-210 quant; reader: kuiper/source/model/model.cpp:52-122, llama3.cpp:201-305,307-440).
  * Returns 0 on success. Pointers alias the blob. */
 int kxo_parse_legacy_f32(const void* blob, size_t bytes, kxo_weights* out);
+/* The Qwen2 exporter's fp32 layout (tools/export_qwen2.py:79-134; reader qwen2.cpp:290-427): as
+ * the legacy fp32 layout, but each layer's wq / wk / wv matrix is followed by its bias vector.
+ * De-interleaves into owned storage (never freed: test-sized models). */
+int kxo_parse_qwen2_f32(const void* blob, size_t bytes, kxo_weights* out);
 int kxo_parse_legacy_q8(const void* blob, size_t bytes, kxo_weights* out);
 
 #ifdef __cplusplus

@@ -37,7 +37,8 @@ class Weights(C.Structure):
     _fields_ = ([("cfg", Config)] + [(m + "_f", C.c_void_p) for m in _MATS] +
                 [(m + "_q", C.c_void_p) for m in _MATS] + [(m + "_s", C.c_void_p) for m in _MATS] +
                 [("emb", C.c_void_p), ("attn_norm", C.c_void_p), ("ffn_norm", C.c_void_p),
-                 ("final_norm", C.c_void_p)])
+                 ("final_norm", C.c_void_p), ("bq", C.c_void_p), ("bk", C.c_void_p),
+                 ("bv", C.c_void_p)])
 
 
 _lib = None
@@ -59,6 +60,7 @@ def lib():
         L.kxo_argmax.restype = C.c_int32
         L.kxo_parse_legacy_f32.restype = C.c_int
         L.kxo_parse_legacy_q8.restype = C.c_int
+        L.kxo_parse_qwen2_f32.restype = C.c_int
         _lib = L
     return _lib
 
@@ -210,13 +212,16 @@ class Model:
     """Reference token loop over oracle kernels.  `arrays` maps names to numpy arrays:
     fp32: wq..w3 [L,K,M], cls [V,dim]; quant: wq_q/wq_s ...; emb, attn_norm, ffn_norm, final_norm."""
 
-    def __init__(self, cfg: Config, arrays=None, blob=None, quant=False):
+    def __init__(self, cfg: Config, arrays=None, blob=None, quant=False, qkv_bias=False):
         self.cfg = cfg
         self._keep = []
         self.w = Weights()
         if blob is not None:
             self._blob = np.frombuffer(blob, np.uint8).copy()
-            fn = lib().kxo_parse_legacy_q8 if quant else lib().kxo_parse_legacy_f32
+            if qkv_bias and quant:
+                raise ValueError("the quant layout carries no biases; attach them with set_bias()")
+            fn = (lib().kxo_parse_legacy_q8 if quant else
+                  lib().kxo_parse_qwen2_f32 if qkv_bias else lib().kxo_parse_legacy_f32)
             rc = fn(_p(self._blob), C.c_size_t(self._blob.size), C.byref(self.w))
             if rc != 0:
                 raise ValueError(f"oracle model parse failed rc={rc}")
@@ -231,7 +236,7 @@ class Model:
                 dt = np.int8 if name.endswith("_q") else np.float32
                 a = np.ascontiguousarray(arr, dt)
                 self._keep.append(a)
-                field = name if name in ("emb", "attn_norm", "ffn_norm", "final_norm") else name
+                field = name
                 if field in _MATS:  # bare name = fp32 matrix
                     field = field + "_f"
                 setattr(self.w, field, a.ctypes.data)
@@ -242,6 +247,13 @@ class Model:
             lib().kxo_state_free(self.st)
         except Exception:
             pass
+
+    def set_bias(self, bq, bk, bv):
+        """q/k/v biases [L][rows] added after the matmuls (the quant files carry none)."""
+        for name, arr in (("bq", bq), ("bk", bk), ("bv", bv)):
+            a = np.ascontiguousarray(arr, np.float32)
+            self._keep.append(a)
+            setattr(self.w, name, a.ctypes.data)
 
     def forward(self, token, pos, threads=1):
         lib().kxo_forward_token(C.byref(self.w), self.st, C.c_int32(int(token)), C.c_int32(int(pos)),

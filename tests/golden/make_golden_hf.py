@@ -1,0 +1,166 @@
+"""Generates the half-split-RoPE fixtures g6 (Llama-3 family) and g7 (Qwen2 family).
+
+The reference's own route from a Hugging Face checkpoint to its on-disk layout is
+tools/export_llama3.py::load_hf_model (no q/k permutation, so the file keeps HF's half-split
+rotary pairing that the C++ side handles under LLAMA3_SUPPORT / QWEN2_SUPPORT) followed by
+legacy_export / legacy_export_quant; tools/export_qwen2.py is the Qwen2 twin (fp32 files carry
+q/k/v biases, quant files carry none).  This script builds tiny random-init HF models offline,
+sends them through exactly those functions, and records what the HF model itself computes
+(fp32 logits for every prefix of a fixed prompt and a 16-token greedy stream) as the expected
+values.  Run in the authoring container only; the reference never travels, only the vectors do.
+
+    python tests/golden/make_golden_hf.py
+
+  g6_llama3_q8.bin   export_llama3.legacy_export_quant of a LlamaForCausalLM
+                     (dim 256, 2 layers, 4 heads, 2 kv heads, head 64, theta 5e5, eps 1e-5)
+  g6_llama3_q8.npz   tokens, logits, greedy of the HF model holding the dequantised weights
+  g7_qwen2_fp32.bin  export_qwen2.legacy_export of a Qwen2ForCausalLM with non-zero q/k/v biases
+                     (dim 128, 2 layers, 2 heads, 1 kv head, head 64, theta 1e6, eps 1e-6)
+  g7_qwen2_fp32.npz  tokens, logits, greedy of the HF model
+  g7_qwen2_q8.bin    export_qwen2.legacy_export_quant of the same model (no biases in the file)
+  g7_qwen2_q8.npz    logits/greedy of the HF model with dequantised weights, once with the biases
+                     zeroed (what the file alone describes) and once with them kept
+                     (logits_bias/greedy_bias; bq, bk, bv are stored so a test can attach them)
+"""
+import copy
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REF_TOOLS = "/root/reference/tools"
+sys.path.insert(0, REF_TOOLS)
+HERE = os.path.dirname(os.path.abspath(__file__))
+GS = 64
+LINEARS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+def _shape_weights(m, seed, dim):
+    """Random-init logits at std 0.02 are nearly flat: scale the embedding and give the norm
+    weights structure so that the greedy argmax has a margin far above fp32 reordering noise."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        m.model.embed_tokens.weight.mul_(40.0)
+        for layer in m.model.layers:
+            layer.input_layernorm.weight.copy_(1.0 + 0.1 * torch.randn(dim, generator=g))
+            layer.post_attention_layernorm.weight.copy_(1.0 + 0.1 * torch.randn(dim, generator=g))
+            for name in ("q_proj", "k_proj", "v_proj"):
+                lin = getattr(layer.self_attn, name)
+                lin.weight.mul_(3.0)  # attention logits that actually discriminate positions
+                if lin.bias is not None:
+                    lin.bias.copy_(0.3 * torch.randn(lin.bias.shape, generator=g))
+        m.model.norm.weight.copy_(1.0 + 0.1 * torch.randn(dim, generator=g))
+        m.lm_head.weight.mul_(4.0)
+
+
+@torch.no_grad()
+def _expected(m, tokens):
+    logits = [m(tokens[None, :n]).logits[0, -1].float().numpy() for n in range(1, len(tokens) + 1)]
+    seq = tokens.clone()
+    greedy, margin = [], np.inf
+    for _ in range(16):
+        lg = m(seq[None, :]).logits[0, -1]
+        top = torch.topk(lg, 2).values
+        margin = min(margin, float(top[0] - top[1]) / float(lg.abs().max()))
+        nxt = int(torch.argmax(lg))
+        greedy.append(nxt)
+        seq = torch.cat([seq, torch.tensor([nxt])])
+    return np.stack(logits), np.array(greedy, np.int32), margin
+
+
+@torch.no_grad()
+def _dequantised_copy(m, quantize_q80, zero_bias):
+    d = copy.deepcopy(m)
+    mods = [d.lm_head]
+    for layer in d.model.layers:
+        mods += [getattr(layer.self_attn, n) for n in LINEARS[:4]]
+        mods += [getattr(layer.mlp, n) for n in LINEARS[4:]]
+    for lin in mods:
+        q, s, _ = quantize_q80(lin.weight.detach(), GS)
+        lin.weight.copy_((q.float().reshape(-1, GS) * s[:, None]).reshape(lin.weight.shape))
+        if zero_bias and lin.bias is not None:
+            lin.bias.zero_()
+    return d
+
+
+def _pick_tokens(models, seed0, min_margin=5e-3):
+    """First prompt seed (counting up from seed0) whose greedy run keeps a relative top-1 margin
+    of at least min_margin on every model given: the stream is then safe to compare token-exact."""
+    for seed in range(seed0, seed0 + 200):
+        tokens = torch.randint(0, 128, (12,), generator=torch.Generator().manual_seed(seed))
+        res = [_expected(m, tokens) for m in models]
+        if min(r[2] for r in res) >= min_margin:
+            print("prompt seed", seed, "margins", [r[2] for r in res])
+            return tokens, res
+    raise RuntimeError("no prompt seed with an adequate greedy margin")
+
+
+def _export(exporter_module, fn_name, hf_dir, out_path):
+    """load_hf_model looks for ./config.json first; run it from an empty directory so the HF
+    config object is what it reads.  The exporters flip vocab_size's sign in place."""
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as empty:
+        os.chdir(empty)
+        try:
+            model = exporter_module.load_hf_model(hf_dir)
+        finally:
+            os.chdir(cwd)
+    getattr(exporter_module, fn_name)(model, out_path)
+    return model
+
+
+def g6():
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import export_llama3
+    torch.manual_seed(6)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=2, vocab_size=128,
+                      rope_theta=5e5, max_position_embeddings=48, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False, attention_bias=False, mlp_bias=False,
+                      attn_implementation="eager")
+    m = LlamaForCausalLM(cfg).eval().float()
+    _shape_weights(m, 60, 256)
+    with tempfile.TemporaryDirectory() as hf_dir:
+        m.save_pretrained(hf_dir)
+        _export(export_llama3, "legacy_export_quant", hf_dir, os.path.join(HERE, "g6_llama3_q8.bin"))
+    d = _dequantised_copy(m, export_llama3.quantize_q80, zero_bias=False)
+    tokens, [(logits, greedy, _)] = _pick_tokens([d], 43)
+    np.savez(os.path.join(HERE, "g6_llama3_q8.npz"), tokens=tokens.numpy().astype(np.int32),
+             logits=logits, greedy=greedy)
+
+
+def g7():
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    import export_qwen2
+    torch.manual_seed(7)
+    cfg = Qwen2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=1, vocab_size=128,
+                      rope_theta=1e6, max_position_embeddings=48, rms_norm_eps=1e-6,
+                      tie_word_embeddings=False, use_sliding_window=False,
+                      attn_implementation="eager")
+    m = Qwen2ForCausalLM(cfg).eval().float()
+    _shape_weights(m, 70, 128)
+    with tempfile.TemporaryDirectory() as hf_dir:
+        m.save_pretrained(hf_dir)
+        _export(export_qwen2, "legacy_export", hf_dir, os.path.join(HERE, "g7_qwen2_fp32.bin"))
+        _export(export_qwen2, "legacy_export_quant", hf_dir, os.path.join(HERE, "g7_qwen2_q8.bin"))
+    nb = _dequantised_copy(m, export_qwen2.quantize_q80, zero_bias=True)
+    wb = _dequantised_copy(m, export_qwen2.quantize_q80, zero_bias=False)
+    tokens, [(logits, greedy, _), (l0, g0, _), (l1, g1, _)] = _pick_tokens([m, nb, wb], 44)
+    np.savez(os.path.join(HERE, "g7_qwen2_fp32.npz"), tokens=tokens.numpy().astype(np.int32),
+             logits=logits, greedy=greedy)
+    bias = {n: np.stack([getattr(layer.self_attn, p).bias.detach().numpy()
+                         for layer in m.model.layers])
+            for n, p in (("bq", "q_proj"), ("bk", "k_proj"), ("bv", "v_proj"))}
+    np.savez(os.path.join(HERE, "g7_qwen2_q8.npz"), tokens=tokens.numpy().astype(np.int32),
+             logits=l0, greedy=g0, logits_bias=l1, greedy_bias=g1, **bias)
+
+
+if __name__ == "__main__":
+    g6()
+    g7()
+    for f in sorted(os.listdir(HERE)):
+        if f.startswith(("g6", "g7")):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,6 +1,8 @@
 """Pins the CPU oracle (oracle/kx_oracle.c) against
   (a) the known-answer vectors held by the reference's own tests, and
-  (b) fixtures generated from the reference's Python (tests/golden/make_golden.py).
+  (b) fixtures generated from the reference's Python (tests/golden/make_golden.py),
+  (c) fixtures written by the reference's HF exporters from Hugging Face models, with the HF
+      models' own outputs as expected values (tests/golden/make_golden_hf.py).
 CPU only."""
 import numpy as np
 import pytest
@@ -131,6 +133,62 @@ def test_tiny_q8_model_vs_reference_python(golden, golden_bytes):
     scale = np.abs(g["logits"]).max()
     assert np.abs(logits - g["logits"]).max() <= 2e-5 * scale
     assert greedy.tolist() == g["greedy"].tolist()
+
+
+# ---- (c) half-split RoPE families (G6 Llama-3, G7 Qwen2), expected values from Hugging Face ----
+# The files were written by the reference's tools/export_llama3.py / export_qwen2.py from HF
+# models (tests/golden/make_golden_hf.py); the expected logits are the HF models' own.  This pins
+# the half-split pairing (cpu/rope_kernel.cpp:18-42, 58-82), theta 5e5 / 1e6, GQA, eps 1e-6 and
+# the q/k/v bias placement (matmul.cpp:76-79, qwen2.cpp:306-333).
+def _llama3_cfg():
+    return kxo.Config(rope_variant=kxo.ROPE_HALF_SPLIT, rope_theta=5e5, rms_eps=1e-5)
+
+
+def _qwen2_cfg():
+    return kxo.Config(rope_variant=kxo.ROPE_HALF_SPLIT, rope_theta=1e6, rms_eps=1e-6)
+
+
+def test_llama3_q8_model_vs_hf(golden, golden_bytes):
+    g = golden("g6_llama3_q8.npz")
+    m = kxo.Model(_llama3_cfg(), blob=golden_bytes("g6_llama3_q8.bin"), quant=True)
+    c = m.cfg
+    assert (c.dim, c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size, c.seq_len,
+            c.group_size) == (256, 512, 2, 4, 2, 128, 48, 64)
+    logits, greedy = _run_stream(m, g["tokens"], 16)
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * np.abs(g["logits"]).max()
+    assert greedy.tolist() == g["greedy"].tolist()
+    # the interleaved pairing on the same file must NOT reproduce it (the fixture discriminates)
+    wrong = kxo.Model(kxo.Config(rope_variant=kxo.ROPE_INTERLEAVED, rope_theta=5e5, rms_eps=1e-5),
+                      blob=golden_bytes("g6_llama3_q8.bin"), quant=True)
+    lw, _ = _run_stream(wrong, g["tokens"], 0)
+    assert np.abs(lw - g["logits"]).max() > 1e-2 * np.abs(g["logits"]).max()
+
+
+def test_qwen2_fp32_model_with_bias_vs_hf(golden, golden_bytes):
+    g = golden("g7_qwen2_fp32.npz")
+    m = kxo.Model(_qwen2_cfg(), blob=golden_bytes("g7_qwen2_fp32.bin"), quant=False, qkv_bias=True)
+    c = m.cfg
+    assert (c.dim, c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size,
+            c.seq_len) == (128, 256, 2, 2, 1, 128, 48)
+    logits, greedy = _run_stream(m, g["tokens"], 16)
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * np.abs(g["logits"]).max()
+    assert greedy.tolist() == g["greedy"].tolist()
+
+
+def test_qwen2_q8_model_vs_hf(golden, golden_bytes):
+    g = golden("g7_qwen2_q8.npz")
+    # the quant file carries no biases (qwen2.cpp:192-217): bias-free expected values
+    m = kxo.Model(_qwen2_cfg(), blob=golden_bytes("g7_qwen2_q8.bin"), quant=True)
+    logits, greedy = _run_stream(m, g["tokens"], 16)
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * np.abs(g["logits"]).max()
+    assert greedy.tolist() == g["greedy"].tolist()
+    # the same int8 weights with the fp32 file's biases attached
+    mb = kxo.Model(_qwen2_cfg(), blob=golden_bytes("g7_qwen2_q8.bin"), quant=True)
+    mb.set_bias(g["bq"], g["bk"], g["bv"])
+    logits, greedy = _run_stream(mb, g["tokens"], 16)
+    assert np.abs(logits - g["logits_bias"]).max() <= 2e-5 * np.abs(g["logits_bias"]).max()
+    assert greedy.tolist() == g["greedy_bias"].tolist()
+    assert np.abs(g["logits_bias"] - g["logits"]).max() > 1e-2 * np.abs(g["logits"]).max()
 
 
 # ---- support kernels: properties the reference's (disabled) tests state -----------------------
