@@ -197,6 +197,18 @@ int kx_mha_decode_f32(const float* query, const float* key_cache, const float* v
                       int32_t kv_dim, int32_t seq_len, int32_t layer_index, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* The same attention for a caller that has no zeroed workspace, only the reference's score tensor
+ * ([head_num][seq_len] fp32, llama3.cpp:523-525, passed to every MHAKernel call,
+ * kernels_interface.h:22-28): that tensor is allocated un-zeroed and keeps the last call's bytes.
+ * Nothing is assumed about its contents: when it is large enough to serve as split workspace its
+ * ticket words are cleared on `stream` ahead of the launch, otherwise each kv head runs as one
+ * split; head sizes other than 32/64/128 use it as the [head_num][seq_len] score rows it is.
+ * score may be NULL (one split per kv head; tiled head sizes only). */
+int kx_mha_decode_scores_f32(const float* query, const float* key_cache, const float* value_cache,
+                             float* out, int32_t pos, int32_t head_num, int32_t kv_mul,
+                             int32_t head_size, int32_t kv_dim, int32_t seq_len, int32_t layer_index,
+                             float* score, size_t score_bytes, void* stream);
+
 /* Same kernel with the position read from device memory (replayable under graph capture);
  * `max_pos` sizes the grid for the longest context this launch will ever see.  Needs a head
  * size the tiled kernel is built for (32/64/128) and kv_mul <= 16. */
@@ -270,6 +282,14 @@ int kx_sin_cos_cache_f32(int32_t head_size, int32_t max_seq_len, float theta, fl
 int kx_rope_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size, float* q, float* k,
                 int32_t k_stride, int32_t pos, int32_t rows, const float* sin_cache,
                 const float* cos_cache, void* stream);
+/* kx_rope_f32 with the q/k/v biases of a Qwen2-style attention block added first (the bias add
+ * of MatmulLayer::forward, matmul.cpp:76-79, sits between the matmul and the RoPE layer:
+ * qwen2.cpp attention_qkv).  bq [dim], bk / bv [kv_dim], each nullable; v rows (stride v_stride)
+ * are touched only to receive bv. */
+int kx_rope_bias_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size, float* q,
+                     float* k, int32_t k_stride, float* v, int32_t v_stride, const float* bq,
+                     const float* bk, const float* bv, int32_t pos, int32_t rows,
+                     const float* sin_cache, const float* cos_cache, void* stream);
 /* swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): out = in1*sigmoid(in1)*in2. */
 int kx_swiglu_f32(const float* in1, const float* in2, float* out, int32_t n, void* stream);
 /* Row-batched form over a stacked [gate | up] buffer: out[t][h] = silu(in[t][h]) * in[t][half+h]. */

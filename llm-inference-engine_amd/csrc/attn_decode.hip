@@ -414,10 +414,15 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   if (nsplit == 1) return;
 
   // ---- the workgroup that arrives last for this kv head combines the splits ----
-  // Every storing wave drains its write-through stores before the workgroup takes a ticket.
+  // Every storing wave drains its write-through stores before the workgroup takes a ticket; the
+  // barrier orders them (workgroup scope) before thread 0's release fence, which publishes them
+  // at device scope ahead of the ticket.  The stores are write-through already, so the fence's
+  // cache write-back finds nothing of this kernel's to do; it is what makes the hand-off a
+  // release/acquire pair in the memory model instead of a property of how the stores are emitted.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned old = atomicInc(&tickets[kvh * (kTicketStride / sizeof(unsigned))], (unsigned)nsplit - 1u);  // wraps back to 0
     sm_last = old == (unsigned)nsplit - 1u;
   }
@@ -643,6 +648,42 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
   return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
                            head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
                            stream);
+}
+
+extern "C" int kx_mha_decode_scores_f32(const float* query, const float* key_cache,
+                                        const float* value_cache, float* out, int32_t pos,
+                                        int32_t head_num, int32_t kv_mul, int32_t head_size,
+                                        int32_t kv_dim, int32_t seq_len, int32_t layer_index,
+                                        float* score, size_t score_bytes, void* stream) {
+  using namespace kx;
+  const bool tiled = kv_mul > 0 && kv_mul <= 16 &&
+                     (head_size == 32 || head_size == 64 || head_size == 128);
+  if (!tiled) {
+    // the generic kernel keeps its scores in [head_num][seq_len] rows: the score tensor itself,
+    // without the ticket words that head a workspace (they would not fit behind it)
+    if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
+    if (pos < 0 || pos >= seq_len || head_num <= 0 || kv_mul <= 0 || head_num % kv_mul) return KX_EINVAL;
+    if (kv_dim != head_num / kv_mul * head_size) return KX_EINVAL;
+    if (!score || score_bytes < (size_t)head_num * seq_len * sizeof(float)) return KX_EWORKSPACE;
+    const size_t layer_off = (size_t)layer_index * (size_t)seq_len * (size_t)kv_dim;
+    hipLaunchKernelGGL(attn_decode_generic_kernel, dim3(head_num), dim3(256), 0, (hipStream_t)stream,
+                       query, key_cache + layer_off, value_cache + layer_off, out, score, pos, kv_mul,
+                       kv_dim, head_size, seq_len, 1.0f / sqrtf((float)head_size));
+    KX_LAUNCH_CHECK();
+    return KX_OK;
+  }
+  // Tiled kernel: the tensor serves as split workspace when it holds the ticket words and at
+  // least two splits; its bytes are whatever the last call left, so the tickets are cleared on
+  // the stream first.  A smaller tensor means one split per kv head and no workspace at all.
+  const size_t per_split = (size_t)head_num * attn_ws_stride(head_size) * sizeof(float);
+  if (score && ((uintptr_t)score % 16 == 0) && score_bytes >= kTicketBytes + 2 * per_split) {
+    KX_HIP_TRY(hipMemsetAsync(score, 0, kTicketBytes, (hipStream_t)stream));
+    return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num,
+                                    kv_mul, head_size, kv_dim, seq_len, layer_index, score,
+                                    score_bytes, stream);
+  }
+  return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
+                                  head_size, kv_dim, seq_len, layer_index, nullptr, 0, stream);
 }
 
 extern "C" int kx_mha_decode_dpos_f32(const float* query, const float* key_cache,

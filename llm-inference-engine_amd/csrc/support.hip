@@ -88,10 +88,20 @@ __global__ void sin_cos_kernel(int head_size, int max_seq_len, float theta, floa
 
 // rope_kernel_cu_fp32 (cuda/rope_kernel.cu:5-36 half-split, :98-128 interleaved).
 // One thread per rotation pair of q; pairs inside kv_dim also rotate k.
+// Optional q/k/v biases (added ahead of the rotation, as MatmulLayer adds them ahead of the RoPE
+// layer: matmul.cpp:76-79, qwen2.cpp attention_qkv); v is touched only to receive its bias.
+struct RopeBias {
+  const float* bq;
+  const float* bk;
+  const float* bv;
+  float* v;
+  int v_stride;
+};
+
 template <int VARIANT>
 __global__ void rope_kernel(int dim, int kv_dim, int head_size, float* q, float* k, int k_stride,
                             int pos, int rows, const float* __restrict__ sin_cache,
-                            const float* __restrict__ cos_cache) {
+                            const float* __restrict__ cos_cache, const RopeBias b) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = blockIdx.y;
   if (pair >= dim / 2 || row >= rows) return;
@@ -111,15 +121,28 @@ __global__ void rope_kernel(int dim, int kv_dim, int head_size, float* q, float*
   const float fci = sin_cache[(size_t)p * head_size + tab];
   const float fcr = cos_cache[(size_t)p * head_size + tab];
   float* qr = q + (size_t)row * dim;
-  const float q0 = qr[i0], q1 = qr[i1];
+  float q0 = qr[i0], q1 = qr[i1];
+  if (b.bq) {
+    q0 += b.bq[i0];
+    q1 += b.bq[i1];
+  }
   qr[i0] = q0 * fcr - q1 * fci;
   qr[i1] = q0 * fci + q1 * fcr;
   const int head_base = VARIANT == KX_ROPE_INTERLEAVED ? i0 : (i0 / head_size) * head_size;
   if (head_base < kv_dim) {
     float* kr = k + (size_t)row * k_stride;
-    const float k0 = kr[i0], k1 = kr[i1];
+    float k0 = kr[i0], k1 = kr[i1];
+    if (b.bk) {
+      k0 += b.bk[i0];
+      k1 += b.bk[i1];
+    }
     kr[i0] = k0 * fcr - k1 * fci;
     kr[i1] = k0 * fci + k1 * fcr;
+    if (b.bv) {
+      float* vr = b.v + (size_t)row * b.v_stride;
+      vr[i0] += b.bv[i0];
+      vr[i1] += b.bv[i1];
+    }
   }
 }
 
@@ -360,25 +383,36 @@ extern "C" int kx_sin_cos_cache_f32(int32_t head_size, int32_t max_seq_len, floa
   return KX_OK;
 }
 
-extern "C" int kx_rope_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size, float* q,
-                           float* k, int32_t k_stride, int32_t pos, int32_t rows,
-                           const float* sin_cache, const float* cos_cache, void* stream) {
+extern "C" int kx_rope_bias_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size,
+                                float* q, float* k, int32_t k_stride, float* v, int32_t v_stride,
+                                const float* bq, const float* bk, const float* bv, int32_t pos,
+                                int32_t rows, const float* sin_cache, const float* cos_cache,
+                                void* stream) {
   if (!q || !k || !sin_cache || !cos_cache) return KX_EINVAL;
   if (dim <= 0 || head_size <= 0 || head_size % 2 || dim % head_size || kv_dim % head_size ||
-      rows <= 0 || pos < 0)
+      kv_dim > dim || rows <= 0 || pos < 0)
     return KX_EINVAL;
+  if (bv && !v) return KX_EINVAL;
+  const kx::RopeBias b{bq, bk, bv, v, v_stride};
   const dim3 grid((dim / 2 + 127) / 128, rows);
   if (variant == KX_ROPE_INTERLEAVED) {
     hipLaunchKernelGGL(rope_kernel<KX_ROPE_INTERLEAVED>, grid, dim3(128), 0, (hipStream_t)stream,
-                       dim, kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache);
+                       dim, kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache, b);
   } else if (variant == KX_ROPE_HALF_SPLIT) {
     hipLaunchKernelGGL(rope_kernel<KX_ROPE_HALF_SPLIT>, grid, dim3(128), 0, (hipStream_t)stream, dim,
-                       kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache);
+                       kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache, b);
   } else {
     return KX_EINVAL;
   }
   KX_LAUNCH_CHECK();
   return KX_OK;
+}
+
+extern "C" int kx_rope_f32(int32_t variant, int32_t dim, int32_t kv_dim, int32_t head_size, float* q,
+                           float* k, int32_t k_stride, int32_t pos, int32_t rows,
+                           const float* sin_cache, const float* cos_cache, void* stream) {
+  return kx_rope_bias_f32(variant, dim, kv_dim, head_size, q, k, k_stride, nullptr, 0, nullptr,
+                          nullptr, nullptr, pos, rows, sin_cache, cos_cache, stream);
 }
 
 extern "C" int kx_swiglu_f32(const float* in1, const float* in2, float* out, int32_t n,

@@ -20,6 +20,7 @@ typedef struct kxm_config {
   float rms_eps;
   int32_t tp_size, tp_rank;
   int32_t kv_f16;       /* non-zero: 16-bit (IEEE half) KV cache instead of the reference's fp32 one */
+  int32_t qkv_bias;     /* non-zero: q/k/v projections carry fp32 biases (Qwen2 family) */
 } kxm_config;
 
 const char* kxm_last_error(void);
@@ -27,6 +28,8 @@ void* kxm_create(const kxm_config* cfg);
 void kxm_destroy(void* model);
 int kxm_init_synthetic(void* model, uint64_t seed);
 int kxm_load_blob(void* model, const void* blob, size_t bytes);
+/* q/k/v biases of one layer, host arrays of the unsharded sizes [dim], [kv_dim], [kv_dim] */
+int kxm_set_qkv_bias(void* model, int32_t layer, const float* bq, const float* bk, const float* bv);
 int kxm_read_weight(void* model, const char* name, int32_t layer, void* host_out, size_t bytes);
 /* Tensor-parallel shard plan (pure host logic, callable without a GPU): {row0, rows, col0, cols}
  * for wq, wk, wv, wo, w1, w2, w3 in that order; -1 when the geometry does not divide. */
@@ -64,6 +67,15 @@ int kxm_test_matmul_layer(const float* x, const void* w, const float* scales, in
 int kxm_test_mha_layer(const float* q, const float* kcache, const float* vcache, int32_t layers,
                        int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
                        int32_t layer_idx, int32_t pos, float* out);
+/* The same layer with NO reserved workspace and a garbage-filled score tensor (the state a
+ * drop-in caller hands over), run twice in a row. */
+int kxm_test_mha_layer_no_workspace(const float* q, const float* kcache, const float* vcache,
+                                    int32_t layers, int32_t seq_len, int32_t head_num,
+                                    int32_t kv_mul, int32_t head_size, int32_t layer_idx,
+                                    int32_t pos, float* out);
+/* 1 when a row-parallel MatmulLayer (tp_size 2) without a communicator refuses to run, 0 when it
+ * returned success. */
+int kxm_test_matmul_tp_without_comm(void);
 int kxm_test_flash_layer(const float* q, const float* kcache, const float* vcache, int32_t layers,
                          int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
                          int32_t layer_idx, int32_t pos, int32_t tq, float* out);

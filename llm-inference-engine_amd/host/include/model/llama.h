@@ -58,6 +58,10 @@ struct TransformerConfig {
   // 16-bit KV cache: rows are kept as IEEE half (one rounding per stored element); the fused token
   // loop and the batched prompt pass support it, the layer-by-layer loop (fp32 views) does not
   bool kv_f16 = false;
+  // Qwen2-style attention: fp32 biases on the q/k/v projections.  The fp32 files carry them
+  // (tools/export_qwen2.py:102-110, qwen2.cpp:306-333); quant files carry none (qwen2.cpp:192-217),
+  // so a quant model starts with zero biases and set_qkv_bias() may attach them.
+  bool qkv_bias = false;
   // derived (model.cpp:132-134)
   int32_t kv_dim = 0, kv_mul = 0, head_size = 0;
   // per-rank sizes under tensor parallelism
@@ -84,8 +88,11 @@ class LlamaModel {
   // (:134-210), chosen by cfg.group_size; reader logic of model.cpp:52-122, llama3.cpp:201-440.
   // Tensor-parallel ranks take their shard of every matrix.
   base::Status load_blob(const void* blob, size_t bytes);
+  // q/k/v biases of one layer from host arrays of the UNSHARDED sizes ([dim], [kv_dim], [kv_dim];
+  // a tensor-parallel rank keeps its heads' rows).  Needs cfg.qkv_bias.
+  base::Status set_qkv_bias(int32_t layer, const float* bq, const float* bk, const float* bv);
   // Host copy of one weight as stored on this rank.  name: wq wk wv wo w1 w2 w3 cls (int8 or fp32
-  // data), *_s (scales), emb, attn_norm, ffn_norm, final_norm.
+  // data), *_s (scales), emb, attn_norm, ffn_norm, final_norm, bq bk bv (biases, cfg.qkv_bias).
   base::Status read_weight(const std::string& name, int32_t layer, void* host_out, size_t bytes) const;
 
   base::Status init_comm(const base::CommUniqueId* id);

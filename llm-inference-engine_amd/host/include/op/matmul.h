@@ -3,6 +3,8 @@
 // Weight [dim0, dim1] = [out, in]; fp32, or int8 with per-group fp32 scales.
 #ifndef KX_HOST_OP_MATMUL_H_
 #define KX_HOST_OP_MATMUL_H_
+#include <functional>
+
 #include "op/layer.h"
 
 namespace op {
@@ -26,6 +28,11 @@ class MatmulLayer : public LayerParam {
   // Column-parallel layers (Wq/Wk/Wv/W1/W3) need no exchange; row-parallel layers (Wo/W2) sum
   // their partial outputs across ranks: need_all_reduce = true (matmul.h:28-42).
   void set_tp_config(int32_t tp_size, int32_t tp_rank, bool need_all_reduce = false);
+  // Optional: the sum over ranks is delegated to the owner (a model routes it through its own
+  // all-reduce, which may be RCCL on the side stream or a test rendezvous).  Without a reducer the
+  // layer uses the RcclHandler singleton and fails when that has no communicator of tp_size ranks.
+  using Reducer = std::function<base::Status(float* data, size_t count)>;
+  void set_reducer(Reducer reducer) { reducer_ = std::move(reducer); }
 
   int32_t dim0() const { return dim0_; }
   int32_t dim1() const { return dim1_; }
@@ -38,6 +45,7 @@ class MatmulLayer : public LayerParam {
   int32_t tp_size_ = 1;
   int32_t tp_rank_ = 0;
   bool need_all_reduce_ = false;
+  Reducer reducer_;
 };
 }  // namespace op
 #endif

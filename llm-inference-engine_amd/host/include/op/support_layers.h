@@ -13,9 +13,13 @@ class RmsNormLayer : public LayerParam {
   base::Status check() const override;
   using Layer::forward;  // keep the forward(in..., out) overloads visible
   base::Status forward() override;
+  // epsilon of this layer's model (the reference compiles 1e-5 or 1e-6 in,
+  // cpu/rmsnorm_kernel.cpp:24-28); unset = the thread's kernel::model_knobs() value
+  void set_eps(float eps) { eps_ = eps; }
 
  private:
   int32_t dim_ = 0;
+  float eps_ = -1.f;
 };
 
 // inputs: q, k, pos (host int32), sin table, cos table; rotates q and k in place
@@ -25,11 +29,15 @@ class RoPELayer : public Layer {
   base::Status check() const override;
   using Layer::forward;  // keep the forward(in..., out) overloads visible
   base::Status forward() override;
+  // pairing of this layer's model: 0 interleaved, 1 half split (the reference's LLAMA3_SUPPORT /
+  // QWEN2_SUPPORT switch, cpu/rope_kernel.cpp:3,43,83); unset = kernel::model_knobs()
+  void set_rope_variant(int32_t variant) { variant_ = variant; }
 
  private:
   int32_t dim_ = 0;
   int32_t kv_dim_ = 0;
   int32_t head_size_ = 0;
+  int32_t variant_ = -1;
 };
 
 class VecAddLayer : public Layer {

@@ -38,6 +38,7 @@ void* kxm_create(const kxm_config* c) {
   t.rope_theta = c->rope_theta; t.rms_eps = c->rms_eps;
   t.tp_size = c->tp_size < 1 ? 1 : c->tp_size; t.tp_rank = c->tp_rank;
   t.kv_f16 = c->kv_f16 != 0;
+  t.qkv_bias = c->qkv_bias != 0;
   auto* m = new model::LlamaModel();
   base::Status s = m->init(t);
   if (!s) {
@@ -50,6 +51,9 @@ void* kxm_create(const kxm_config* c) {
 void kxm_destroy(void* m) { delete M(m); }
 int kxm_init_synthetic(void* m, uint64_t seed) { return done(M(m)->init_synthetic(seed)); }
 int kxm_load_blob(void* m, const void* blob, size_t bytes) { return done(M(m)->load_blob(blob, bytes)); }
+int kxm_set_qkv_bias(void* m, int32_t layer, const float* bq, const float* bk, const float* bv) {
+  return done(M(m)->set_qkv_bias(layer, bq, bk, bv));
+}
 int kxm_read_weight(void* m, const char* name, int32_t layer, void* out, size_t bytes) {
   return done(M(m)->read_weight(name, layer, out, bytes));
 }
@@ -158,10 +162,12 @@ int kxm_test_matmul_layer(const float* x, const void* w, const float* scales, in
 
 static int attn_common(bool flash, const float* q, const float* kc, const float* vc, int32_t layers,
                        int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,
-                       int32_t layer_idx, int32_t pos, int32_t tq, float* out_host) {
+                       int32_t layer_idx, int32_t pos, int32_t tq, float* out_host,
+                       bool reserve_workspace = true) {
   auto cfg = std::make_shared<kernel::CudaConfig>();
   if (int rc = cfg->create_streams()) return rc;
-  if (int rc = cfg->reserve_attn_workspace(head_num, head_num / kv_mul, head_size, seq_len)) return rc;
+  if (reserve_workspace)
+    if (int rc = cfg->reserve_attn_workspace(head_num, head_num / kv_mul, head_size, seq_len)) return rc;
   const int32_t kv_dim = head_num / kv_mul * head_size;
   const base::DataType f32 = base::DataType::kDataTypeFp32;
   tensor::Tensor key = dev_from_host(f32, {layers, seq_len, kv_dim}, kc);
@@ -181,7 +187,11 @@ static int attn_common(bool flash, const float* q, const float* kc, const float*
     layer.set_pos(pos);
     layer.set_layer_idx(layer_idx);
     tensor::Tensor score = dev_from_host(f32, {head_num, seq_len}, nullptr);
+    // the reference allocates this tensor un-zeroed and leaves probabilities in it
+    // (llama3.cpp:523-525): without a reserved workspace the layer must cope with any bytes
+    if (!reserve_workspace) kx_memset(score.ptr<void>(), 0xFF, score.byte_size(), nullptr);
     s = layer.forward(query, score, key, val, out);
+    if (s && !reserve_workspace) s = layer.forward(query, score, key, val, out);  // and with its own leftovers
   }
   if (!s) return fail(s);
   kx_stream_sync(cfg->stream);
@@ -195,6 +205,31 @@ int kxm_test_mha_layer(const float* q, const float* kc, const float* vc, int32_t
                        int32_t layer_idx, int32_t pos, float* out) {
   return attn_common(false, q, kc, vc, layers, seq_len, head_num, kv_mul, head_size, layer_idx, pos,
                      1, out);
+}
+int kxm_test_mha_layer_no_workspace(const float* q, const float* kc, const float* vc, int32_t layers,
+                                    int32_t seq_len, int32_t head_num, int32_t kv_mul,
+                                    int32_t head_size, int32_t layer_idx, int32_t pos, float* out) {
+  return attn_common(false, q, kc, vc, layers, seq_len, head_num, kv_mul, head_size, layer_idx, pos,
+                     1, out, false);
+}
+int kxm_test_matmul_tp_without_comm(void) {
+  // a row-parallel layer of a 2-rank group with no communicator behind it must fail, not return
+  // its unreduced partial sum
+  auto cfg = std::make_shared<kernel::CudaConfig>();
+  if (int rc = cfg->create_streams()) return rc;
+  op::MatmulLayer layer(kHip, 4, 8, false, false);
+  layer.set_cuda_config(cfg);
+  std::vector<float> w(32, 1.f), x(8, 1.f);
+  layer.set_weight(0, {4, 8}, w.data(), base::DeviceType::kDeviceCPU);
+  layer.to_cuda();
+  layer.set_tp_config(2, 0, true);
+  tensor::Tensor in = dev_from_host(base::DataType::kDataTypeFp32, {8}, x.data());
+  tensor::Tensor out = dev_from_host(base::DataType::kDataTypeFp32, {4}, nullptr);
+  base::Status s = layer.forward(in, out);
+  kx_stream_sync(cfg->stream);
+  if (s) return 0;
+  fail(s);
+  return 1;
 }
 int kxm_test_flash_layer(const float* q, const float* kc, const float* vc, int32_t layers,
                          int32_t seq_len, int32_t head_num, int32_t kv_mul, int32_t head_size,

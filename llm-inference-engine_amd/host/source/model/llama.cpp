@@ -142,13 +142,12 @@ base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
   hip_ = std::make_shared<kernel::CudaConfig>();
   KX_RET(hip_->create_streams());  // llama3.cpp:124-128
   KX_RET(hip_->reserve_attn_workspace(cfg_.head_local, cfg_.kv_head_local, cfg_.head_size, cfg_.seq_len));
-  kernel::model_knobs().rope_variant = cfg_.rope_variant;
-  kernel::model_knobs().rms_eps = cfg_.rms_eps;
 
   const int32_t dim = cfg_.dim;
   layers_.resize(cfg_.layer_num);
   for (auto& l : layers_) {
     ST_RET(alloc_linear(l.qkv, cfg_.q_dim_local + 2 * cfg_.kv_dim_local, dim));
+    if (cfg_.qkv_bias) ST_RET(dev_alloc(l.qkv.bias, cfg_.q_dim_local + 2 * cfg_.kv_dim_local));
     ST_RET(alloc_linear(l.wo, dim, cfg_.q_dim_local));
     ST_RET(alloc_linear(l.w13, 2 * cfg_.hidden_local, dim));
     ST_RET(alloc_linear(l.w2, dim, cfg_.hidden_local));
@@ -228,6 +227,16 @@ base::Status LlamaModel::init_synthetic(uint64_t seed) {
     ST_RET(fill(lw.w13, 0, sp.w1, c.dim, 4));
     ST_RET(fill(lw.w13, c.hidden_local, sp.w3, c.dim, 6));
     ST_RET(fill(lw.w2, 0, sp.w2, c.hidden_dim, 5));
+    if (c.qkv_bias) {
+      // element r of a rank's bias slice is element (row0 + r) of the unsharded bias vector
+      auto fill_bias = [&](int32_t dst, const ShardSlice& sl, int m) {
+        return kx_fill_hash_f32(lw.qkv.bias + dst, 1, sl.rows, (int64_t)1 << 40, 0, sl.row0, sd(m),
+                                -0.5f, 0.5f, st);
+      };
+      KX_RET(fill_bias(0, sp.wq, 8));
+      KX_RET(fill_bias(c.q_dim_local, sp.wk, 9));
+      KX_RET(fill_bias(c.q_dim_local + c.kv_dim_local, sp.wv, 10));
+    }
     KX_RET(kx_memcpy_h2d(lw.attn_norm, ones.data(), c.dim * sizeof(float), nullptr));
     KX_RET(kx_memcpy_h2d(lw.ffn_norm, ones.data(), c.dim * sizeof(float), nullptr));
   }
@@ -314,6 +323,21 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
     p += L * msize(rows, cols);
     return base::error::Success();
   };
+  // fp32 matrices each followed by their bias vector (tools/export_qwen2.py:102-110; reader
+  // qwen2.cpp:306-333): the rank's rows of the bias go to qkv.bias at dst_off
+  auto upload_kind_bias = [&](size_t rows, size_t cols, auto&& per_layer, int32_t dst_off,
+                              const ShardSlice& sl) -> base::Status {
+    const size_t block = (rows * cols + rows) * 4;
+    if (p + L * block > end) return base::error::ModelParseError("blob truncated");
+    for (size_t l = 0; l < L; ++l) {
+      const uint8_t* w = p + l * block;
+      ST_RET(per_layer(l, w, nullptr));
+      KX_RET(kx_memcpy_h2d(layers_[l].qkv.bias + dst_off, w + (rows * cols + sl.row0) * 4,
+                           (size_t)sl.rows * 4, nullptr));
+    }
+    p += L * block;
+    return base::error::Success();
+  };
   const float *emb = nullptr, *attn_norm = nullptr, *ffn_norm = nullptr, *final_norm = nullptr;
   const uint8_t* cls_w = nullptr;
   const float* cls_s = nullptr;
@@ -348,9 +372,15 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
     // tools/export_llama.py:96-127
     emb = reinterpret_cast<const float*>(p);        p += V * dim * 4;
     attn_norm = reinterpret_cast<const float*>(p);  p += L * dim * 4;
-    ST_RET(upload_kind(dim, dim, up_q));
-    ST_RET(upload_kind(kvd, dim, up_k));
-    ST_RET(upload_kind(kvd, dim, up_v));
+    if (c.qkv_bias) {
+      ST_RET(upload_kind_bias(dim, dim, up_q, 0, sp.wq));
+      ST_RET(upload_kind_bias(kvd, dim, up_k, ql, sp.wk));
+      ST_RET(upload_kind_bias(kvd, dim, up_v, ql + kl, sp.wv));
+    } else {
+      ST_RET(upload_kind(dim, dim, up_q));
+      ST_RET(upload_kind(kvd, dim, up_k));
+      ST_RET(upload_kind(kvd, dim, up_v));
+    }
     ST_RET(upload_kind(dim, dim, up_o));
     ffn_norm = reinterpret_cast<const float*>(p);   p += L * dim * 4;
     ST_RET(upload_kind(hid, dim, up_1));
@@ -390,6 +420,21 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
   return base::error::Success();
 }
 
+base::Status LlamaModel::set_qkv_bias(int32_t layer, const float* bq, const float* bk,
+                                      const float* bv) {
+  const TransformerConfig& c = cfg_;
+  if (!c.qkv_bias) return base::error::InvalidArgument("the model was created without qkv_bias");
+  if (layer < 0 || layer >= c.layer_num || !bq || !bk || !bv)
+    return base::error::InvalidArgument("bad layer or null bias");
+  float* dst = layers_[layer].qkv.bias;
+  KX_RET(kx_stream_sync(hip_->stream));
+  KX_RET(kx_memcpy_h2d(dst, bq + c.plan.wq.row0, (size_t)c.q_dim_local * 4, nullptr));
+  KX_RET(kx_memcpy_h2d(dst + c.q_dim_local, bk + c.plan.wk.row0, (size_t)c.kv_dim_local * 4, nullptr));
+  KX_RET(kx_memcpy_h2d(dst + c.q_dim_local + c.kv_dim_local, bv + c.plan.wv.row0,
+                       (size_t)c.kv_dim_local * 4, nullptr));
+  return base::error::Success();
+}
+
 base::Status LlamaModel::read_weight(const std::string& name, int32_t layer, void* host_out,
                                      size_t bytes) const {
   const TransformerConfig& c = cfg_;
@@ -420,6 +465,12 @@ base::Status LlamaModel::read_weight(const std::string& name, int32_t layer, voi
     const LayerWeights& lw = layers_[layer];
     if (base_name == "attn_norm") { src = lw.attn_norm; n = (size_t)c.dim * 4; }
     else if (base_name == "ffn_norm") { src = lw.ffn_norm; n = (size_t)c.dim * 4; }
+    else if (base_name == "bq" && lw.qkv.bias) { src = lw.qkv.bias; n = (size_t)c.q_dim_local * 4; }
+    else if (base_name == "bk" && lw.qkv.bias) { src = lw.qkv.bias + c.q_dim_local; n = (size_t)c.kv_dim_local * 4; }
+    else if (base_name == "bv" && lw.qkv.bias) {
+      src = lw.qkv.bias + c.q_dim_local + c.kv_dim_local;
+      n = (size_t)c.kv_dim_local * 4;
+    }
     else if (base_name == "wq") sub(lw.qkv, 0, c.q_dim_local, scales);
     else if (base_name == "wk") sub(lw.qkv, c.q_dim_local, c.kv_dim_local, scales);
     else if (base_name == "wv") sub(lw.qkv, c.q_dim_local + c.kv_dim_local, c.kv_dim_local, scales);
@@ -463,8 +514,15 @@ void LlamaModel::build_layers() {
   const base::DataType wdt = quant_ ? base::DataType::kDataTypeInt8 : base::DataType::kDataTypeFp32;
   const size_t esz = quant_ ? 1 : 4;
   auto make = [&](const Linear& l, int32_t row_off, int32_t rows, bool all_reduce) {
-    auto m = std::make_shared<op::MatmulLayer>(kHip, rows, l.cols, quant_);
+    auto m = std::make_shared<op::MatmulLayer>(kHip, rows, l.cols, quant_, l.bias != nullptr);
     m->set_cuda_config(hip_);
+    if (l.bias) {
+      int32_t n = rows;
+      STATUS_CHECK(m->set_bias(0, n, l.bias + row_off, kHip));
+    }
+    // row-parallel sums go through the model's own all-reduce (RCCL on the side stream, or the
+    // loopback rendezvous of the test rig)
+    if (all_reduce) m->set_reducer([this](float* data, size_t count) { return this->all_reduce(data, count); });
     uint8_t* w = static_cast<uint8_t*>(l.w) + (size_t)row_off * l.cols * esz;
     if (quant_) {
       m->set_group_size(c.group_size);
@@ -493,6 +551,7 @@ void LlamaModel::build_layers() {
   auto norm = [&](float* w) {
     auto n = std::make_shared<op::RmsNormLayer>(kHip, c.dim);
     n->set_cuda_config(hip_);
+    n->set_eps(c.rms_eps);
     STATUS_CHECK(n->set_weight(0, view(base::DataType::kDataTypeFp32, {c.dim}, w)));
     return n;
   };
@@ -501,6 +560,7 @@ void LlamaModel::build_layers() {
   for (int l = 0; l < c.layer_num; ++l) R.rmsnorm.push_back(norm(layers_[l].ffn_norm));
   R.rmsnorm.push_back(norm(final_norm_));
   R.rope = std::make_shared<op::RoPELayer>(kHip, c.q_dim_local, c.kv_dim_local, c.head_size);
+  R.rope->set_rope_variant(c.rope_variant);
   R.mha = std::make_shared<op::MultiHeadAttention>(kHip, 0, c.kv_mul, c.kv_dim_local, c.seq_len,
                                                    c.head_local, c.head_size);
   R.add = std::make_shared<op::VecAddLayer>(kHip);
@@ -832,6 +892,9 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
       float* krow = c.kv_f16 ? KR : static_cast<float*>(k_ptr) + (size_t)p0 * kl;
       float* vrow = c.kv_f16 ? VR : static_cast<float*>(v_ptr) + (size_t)p0 * kl;
+      const float* bq = lw.qkv.bias;  // q | k | v biases of the layer, or none
+      const float* bk = bq ? bq + ql : nullptr;
+      const float* bv = bq ? bq + ql + kl : nullptr;
       if (f16_chunk) {
         // long chunks keep the GEMM inputs in fp16: the norm and the attention kernel write fp16,
         // SwiGLU runs in the epilogue of the W1|W3 GEMM; XN / ATT / HH are reused as fp16 rows
@@ -839,7 +902,8 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
         KX_RET(kx_gemm_w8_f16act_ws(XN, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs,
                                     KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
                                     nullptr, 0, rows, dim, lw.qkv.rows, gws, gemm_ws, st));
-        KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
+        KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
+                                p0, rows, sin_, cos_, st));
         if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
         KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
         KX_RET(kx_gemm_w8_f16act_ws(ATT, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs,
@@ -860,7 +924,8 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
       KX_RET(kx_gemm_w8_f32_ws(XN, dim, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs, Q, ql,
                                krow, kl, vrow, kl, ql, ql + kl, nullptr, 0, rows, dim,
                                lw.qkv.rows, gws, gemm_ws, st));
-      KX_RET(kx_rope_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, p0, rows, sin_, cos_, st));
+      KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
+                              p0, rows, sin_, cos_, st));
       if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
       KX_RET(attention(ATT, nullptr, rows, p0 + rows - 1, l));
       KX_RET(kx_gemm_w8_f32_ws(ATT, ql, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs, X, dim,

@@ -108,14 +108,22 @@ void mha_kernel_hip(int32_t pos, int32_t head_num, int32_t layer_index, int32_t 
                     base::DeviceType device_type, CudaConfig* config) {
   UNUSED(device_type);
   CHECK(config != nullptr);
-  // Scratch: the config's attention workspace when present, else the score tensor the reference
-  // passes for this purpose ([head_num][seq_len], llama3.cpp:523-525).
+  // Scratch: the config's attention workspace (zeroed once by reserve_attn_workspace) when
+  // present.  Else the score tensor the reference passes ([head_num][seq_len], llama3.cpp:523-525):
+  // that one is allocated un-zeroed and still holds the last call's contents, so it goes through
+  // the entry that assumes nothing about its bytes.
+  if (!config->attn_workspace) {
+    ok(kx_mha_decode_scores_f32(query_tensor.ptr<float>(), key_cache_tensor.ptr<float>(),
+                                value_cache_tensor.ptr<float>(), out_ptr<float>(mha_out), pos,
+                                head_num, kv_mul, head_size, kv_dim, seq_len, layer_index,
+                                score_tensor.is_empty() ? nullptr : out_ptr<float>(score_tensor),
+                                score_tensor.is_empty() ? 0 : score_tensor.byte_size(),
+                                config->stream),
+       "kx_mha_decode_scores_f32");
+    return;
+  }
   void* ws = config->attn_workspace;
   size_t ws_bytes = config->attn_workspace_bytes;
-  if (!ws && !score_tensor.is_empty()) {
-    ws = out_ptr<float>(score_tensor);
-    ws_bytes = score_tensor.byte_size();
-  }
   ok(kx_mha_decode_f32(query_tensor.ptr<float>(), key_cache_tensor.ptr<float>(),
                        value_cache_tensor.ptr<float>(), out_ptr<float>(mha_out), pos, head_num,
                        kv_mul, head_size, kv_dim, seq_len, layer_index, ws, ws_bytes,

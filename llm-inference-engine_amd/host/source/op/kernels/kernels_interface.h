@@ -65,13 +65,30 @@ FlashAttentionKernel get_flash_attention_kernel(base::DeviceType device_type);
 
 // Model-level knobs the reference fixes with compile-time macros (LLAMA3_SUPPORT /
 // QWEN2_SUPPORT: cpu/rope_kernel.cpp:3,43,83; cpu/rmsnorm_kernel.cpp:24-28).  The registry
-// signatures have no slot for them, so they are process-wide settings read by the HIP
-// registry functions.  Defaults = the reference's default build (interleaved RoPE, eps 1e-5).
+// signatures have no slot for them.  RmsNormLayer / RoPELayer carry their own values (set_eps,
+// set_rope_variant) and install them for the duration of their kernel call with ScopedKnobs, so
+// two models of different families can live in one process; model_knobs() is the per-thread
+// value a registry function reads, and what a layer that was given no value of its own falls
+// back to.  Defaults = the reference's default build (interleaved RoPE, eps 1e-5).
 struct ModelKnobs {
   int32_t rope_variant = 0;  // KX_ROPE_INTERLEAVED
   float rms_eps = 1e-5f;
 };
 ModelKnobs& model_knobs();
+class ScopedKnobs {
+ public:
+  // negative values keep what is installed already
+  ScopedKnobs(int32_t rope_variant, float rms_eps) : saved_(model_knobs()) {
+    if (rope_variant >= 0) model_knobs().rope_variant = rope_variant;
+    if (rms_eps >= 0.f) model_knobs().rms_eps = rms_eps;
+  }
+  ~ScopedKnobs() { model_knobs() = saved_; }
+  ScopedKnobs(const ScopedKnobs&) = delete;
+  ScopedKnobs& operator=(const ScopedKnobs&) = delete;
+
+ private:
+  ModelKnobs saved_;
+};
 
 // Fills the RoPE tables on the device (sin_cos_cache_calc_cu, cuda/rope_kernel.cu:138-146).
 void sin_cos_cache_calc_hip(int head_size, int max_seq_len, float theta,

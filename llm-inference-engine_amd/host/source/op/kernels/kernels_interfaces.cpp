@@ -6,7 +6,7 @@
 
 namespace kernel {
 ModelKnobs& model_knobs() {
-  static ModelKnobs knobs;
+  static thread_local ModelKnobs knobs;
   return knobs;
 }
 

@@ -82,7 +82,13 @@ base::Status MatmulLayer::forward() {
   if (need_all_reduce_ && tp_size_ > 1 && device_type_ == base::DeviceType::kDeviceHIP) {
     void* ptr = get_output(0).ptr<void>();
     const size_t count = get_output(0).size();
+    if (reducer_) return reducer_(static_cast<float*>(ptr), count);
     auto comm = base::RcclHandler::get_instance();
+    // A partial sum that is never reduced is silent corruption: refuse instead of returning it.
+    if (!comm->raw_comm() || comm->world_size() != tp_size_)
+      return base::error::InternalError(
+          "row-parallel MatmulLayer with tp_size " + std::to_string(tp_size_) +
+          " but no RCCL communicator of that size: call RcclHandler::Init with the unique id first");
     if (cuda_config_->comm_stream && cuda_config_->compute_done && cuda_config_->comm_done) {
       // compute stream -> (event) -> comm stream runs the all-reduce -> (event) -> compute
       // stream.  Same ordering as matmul.cpp:93-116, with the two events owned by the config

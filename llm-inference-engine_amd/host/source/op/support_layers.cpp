@@ -27,6 +27,7 @@ base::Status RmsNormLayer::check() const {
 base::Status RmsNormLayer::forward() {
   auto status = check();
   if (!status) return status;
+  kernel::ScopedKnobs knobs(-1, eps_);
   kernel::get_rmsnorm_kernel(device_type_)(get_input(0), get_weight(0), get_output(0), stream());
   return base::error::Success();
 }
@@ -58,6 +59,7 @@ base::Status RoPELayer::check() const {
 base::Status RoPELayer::forward() {
   auto status = check();
   if (!status) return status;
+  kernel::ScopedKnobs knobs(variant_, -1.f);
   kernel::get_rope_kernel(device_type_)(dim_, kv_dim_, head_size_, get_input(0), get_input(1),
                                         get_input(2), get_input(3), get_input(4), stream());
   return base::error::Success();

@@ -76,6 +76,8 @@ SIGNATURES = {
     "kx_flash_attention_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _sz, _vp]),
+    "kx_mha_decode_scores_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                           _i32, _vp, _sz, _vp]),
     "kx_mha_decode_dpos_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                          _i32, _i32, _vp, _sz, _vp]),
     "kx_flash_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
@@ -88,6 +90,8 @@ SIGNATURES = {
     "kx_rmsnorm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_sin_cos_cache_f32": (C.c_int, [_i32, _i32, _f, _vp, _vp, _vp]),
     "kx_rope_f32": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "kx_rope_bias_f32": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
+                                   _i32, _i32, _vp, _vp, _vp]),
     "kx_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "kx_swiglu_rows_f32": (C.c_int, [_vp, C.c_int64, _i32, _vp, C.c_int64, _i32, _vp]),
     "kx_add_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),

@@ -18,7 +18,7 @@ class Config(C.Structure):
                 ("head_num", C.c_int32), ("kv_head_num", C.c_int32), ("vocab_size", C.c_int32),
                 ("seq_len", C.c_int32), ("group_size", C.c_int32), ("rope_variant", C.c_int32),
                 ("rope_theta", C.c_float), ("rms_eps", C.c_float), ("tp_size", C.c_int32),
-                ("tp_rank", C.c_int32), ("kv_f16", C.c_int32)]
+                ("tp_rank", C.c_int32), ("kv_f16", C.c_int32), ("qkv_bias", C.c_int32)]
 
 
 # the model shapes named by the benchmark configs
@@ -52,6 +52,7 @@ def hlib():
         L.kxm_destroy.argtypes = [_vp]
         L.kxm_init_synthetic.argtypes = [_vp, C.c_uint64]
         L.kxm_load_blob.argtypes = [_vp, _vp, C.c_size_t]
+        L.kxm_set_qkv_bias.argtypes = [_vp, _i32, _vp, _vp, _vp]
         L.kxm_read_weight.argtypes = [_vp, C.c_char_p, _i32, _vp, C.c_size_t]
         L.kxm_comm_unique_id.argtypes = [_vp]
         L.kxm_init_comm.argtypes = [_vp, _vp]
@@ -73,6 +74,7 @@ def hlib():
         L.kxm_stream.argtypes = [_vp]
         L.kxm_test_matmul_layer.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]
         L.kxm_test_mha_layer.argtypes = [_vp, _vp, _vp] + [_i32] * 7 + [_vp]
+        L.kxm_test_mha_layer_no_workspace.argtypes = [_vp, _vp, _vp] + [_i32] * 7 + [_vp]
         L.kxm_test_flash_layer.argtypes = [_vp, _vp, _vp] + [_i32] * 8 + [_vp]
         L.kxm_test_kv_layout.argtypes = [_i32] * 5 + [C.POINTER(C.c_int64)] * 3
         _hlib = L
@@ -89,10 +91,10 @@ def _p(a):
 
 
 class Model:
-    def __init__(self, seq_len, group_size=64, tp_size=1, tp_rank=0, kv_f16=False, **shape):
+    def __init__(self, seq_len, group_size=64, tp_size=1, tp_rank=0, kv_f16=False, qkv_bias=False,
+                 **shape):
         self.cfg = Config(seq_len=seq_len, group_size=group_size, tp_size=tp_size, tp_rank=tp_rank,
-                          kv_f16=1 if kv_f16 else 0,
-                          **shape)
+                          kv_f16=1 if kv_f16 else 0, qkv_bias=1 if qkv_bias else 0, **shape)
         self.h = hlib().kxm_create(C.byref(self.cfg))
         if not self.h:
             raise KxError("kxm_create failed: " + hlib().kxm_last_error().decode())
@@ -120,6 +122,11 @@ class Model:
         buf = np.frombuffer(blob, np.uint8)
         hcheck(hlib().kxm_load_blob(self.h, _p(buf), buf.size), "kxm_load_blob")
 
+    def set_qkv_bias(self, layer, bq, bk, bv):
+        a = [np.ascontiguousarray(b, np.float32) for b in (bq, bk, bv)]
+        hcheck(hlib().kxm_set_qkv_bias(self.h, layer, _p(a[0]), _p(a[1]), _p(a[2])),
+               "kxm_set_qkv_bias")
+
     def weight_shape(self, name):
         c = self.cfg
         gs = c.group_size
@@ -132,6 +139,8 @@ class Model:
         if name.endswith("_s"):
             r, k = shapes[name[:-2]]
             return (r * k // gs,), np.float32
+        if name in ("bq", "bk", "bv"):
+            return (self.q_dim_local if name == "bq" else self.kv_dim_local,), np.float32
         if name == "emb":
             return (c.vocab_size, c.dim), np.float32
         return (c.dim,), np.float32
@@ -272,6 +281,18 @@ def mha_layer(q, kc, vc, head_num, kv_mul, head_size, layer_idx, pos):
                                      _p(np.ascontiguousarray(vc, np.float32)), L, S, head_num,
                                      kv_mul, head_size, layer_idx, pos, _p(out)),
            "MultiHeadAttention::forward")
+    return out.reshape(head_num, head_size)
+
+
+def mha_layer_no_workspace(q, kc, vc, head_num, kv_mul, head_size, layer_idx, pos):
+    L, S, _ = kc.shape
+    out = np.empty(head_num * head_size, np.float32)
+    hcheck(hlib().kxm_test_mha_layer_no_workspace(_p(np.ascontiguousarray(q, np.float32)),
+                                                  _p(np.ascontiguousarray(kc, np.float32)),
+                                                  _p(np.ascontiguousarray(vc, np.float32)), L, S,
+                                                  head_num, kv_mul, head_size, layer_idx, pos,
+                                                  _p(out)),
+           "MultiHeadAttention::forward (no workspace)")
     return out.reshape(head_num, head_size)
 
 

@@ -139,6 +139,162 @@ def test_tiny_q8_prefill_then_graph_decode_token_exact(golden, golden_bytes, exa
         np.testing.assert_allclose(v, ov_[layer, :n], rtol=0, atol=tol * np.abs(ov_[layer, :n]).max())
 
 
+# ---------------- half-split RoPE families: fixtures written by the reference's HF exporters -------
+# g6 / g7 (tests/golden/make_golden_hf.py): files from tools/export_llama3.py / export_qwen2.py,
+# expected logits and greedy streams computed by the Hugging Face models themselves.
+LLAMA3_TINY = dict(dim=256, hidden_dim=512, layer_num=2, head_num=4, kv_head_num=2, vocab_size=128,
+                   rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+QWEN2_TINY = dict(dim=128, hidden_dim=256, layer_num=2, head_num=2, kv_head_num=1, vocab_size=128,
+                  rope_variant=1, rope_theta=1e6, rms_eps=1e-6)
+
+
+def _prefill_decode_exact(make_model, g, logits_key="logits", greedy_key="greedy"):
+    toks = g["tokens"]
+    scale = np.abs(g[logits_key]).max()
+    for exact, tol in ((True, 2e-5), (False, 3e-3)):
+        for use_graph in (False, True):
+            m = make_model()
+            last = m.prefill(toks, exact=exact)
+            assert np.abs(last - g[logits_key][-1]).max() <= tol * scale, (exact, use_graph)
+            m.decode(15, use_graph=use_graph)
+            hist = m.history(len(toks) + 16)
+            assert hist[:len(toks)].tolist() == toks.tolist()
+            assert hist[len(toks):].tolist() == g[greedy_key].tolist(), (exact, use_graph)
+            m.close()
+
+
+def test_llama3_q8_hf_fixture_every_path(golden, golden_bytes):
+    g = golden("g6_llama3_q8.npz")
+    blob = golden_bytes("g6_llama3_q8.bin")
+    scale = np.abs(g["logits"]).max()
+
+    def make():
+        m = host.Model(seq_len=48, group_size=GS, **LLAMA3_TINY)
+        m.load_blob(blob)
+        return m
+    for path in ("forward_layers", "step_logits"):
+        m = make()
+        logits, greedy = _stream(getattr(m, path), g["tokens"], 16)
+        assert np.abs(logits - g["logits"]).max() <= 2e-5 * scale, path
+        assert greedy == g["greedy"].tolist(), path
+        m.close()
+    _prefill_decode_exact(make, g)
+
+
+def test_qwen2_fp32_hf_fixture_with_biases_layer_path(golden, golden_bytes):
+    # fp32 file with q/k/v biases (qwen2.cpp:306-333) through op::MatmulLayer(has_bias) + registry
+    g = golden("g7_qwen2_fp32.npz")
+    m = host.Model(seq_len=48, group_size=0, qkv_bias=True, **QWEN2_TINY)
+    m.load_blob(golden_bytes("g7_qwen2_fp32.bin"))
+    logits, greedy = _stream(m.forward_layers, g["tokens"], 16)
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * np.abs(g["logits"]).max()
+    assert greedy == g["greedy"].tolist()
+
+
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_qwen2_q8_hf_fixture_every_path(golden, golden_bytes, with_bias):
+    # the quant file carries no biases (qwen2.cpp:192-217); attached from the fp32 file's values
+    # they go through the fused GEMV epilogue (decode) and the RoPE pass of the prompt path
+    g = golden("g7_qwen2_q8.npz")
+    blob = golden_bytes("g7_qwen2_q8.bin")
+    lk, gk = ("logits_bias", "greedy_bias") if with_bias else ("logits", "greedy")
+    scale = np.abs(g[lk]).max()
+
+    def make():
+        m = host.Model(seq_len=48, group_size=GS, qkv_bias=with_bias, **QWEN2_TINY)
+        m.load_blob(blob)
+        if with_bias:
+            for layer in range(2):
+                m.set_qkv_bias(layer, g["bq"][layer], g["bk"][layer], g["bv"][layer])
+                np.testing.assert_array_equal(m.read_weight("bk", layer), g["bk"][layer])
+        return m
+    for path in ("forward_layers", "step_logits"):
+        m = make()
+        logits, greedy = _stream(getattr(m, path), g["tokens"], 16)
+        assert np.abs(logits - g[lk]).max() <= 2e-5 * scale, path
+        assert greedy == g[gk].tolist(), path
+        m.close()
+    _prefill_decode_exact(make, g, lk, gk)
+
+
+def test_two_model_families_in_one_process(golden, golden_bytes):
+    # RoPE pairing and RMS epsilon travel with each model's layers: an interleaved / 1e-5 model and
+    # a half-split / 1e-6 model stepped alternately both keep matching their fixtures
+    g4, g7 = golden("g4_tiny_q8.npz"), golden("g7_qwen2_q8.npz")
+    a = host.Model(seq_len=32, group_size=GS, **TINY)
+    a.load_blob(golden_bytes("g4_tiny_q8.bin"))
+    b = host.Model(seq_len=48, group_size=GS, **QWEN2_TINY)
+    b.load_blob(golden_bytes("g7_qwen2_q8.bin"))
+    for pos in range(6):
+        la = a.forward_layers(int(g4["tokens"][pos]), pos)
+        lb = b.forward_layers(int(g7["tokens"][pos]), pos)
+        assert np.abs(la - g4["logits"][pos]).max() <= 2e-5 * np.abs(g4["logits"]).max()
+        assert np.abs(lb - g7["logits"][pos]).max() <= 2e-5 * np.abs(g7["logits"]).max()
+
+
+def test_synthetic_qkv_bias_fused_and_layer_paths_vs_oracle():
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=600,
+                 rope_variant=1, rope_theta=1e6, rms_eps=1e-6)
+    seq_len = 600
+    m = host.Model(seq_len=seq_len, group_size=GS, qkv_bias=True, **shape)
+    m.init_synthetic(13)
+    oracle = _oracle_from(m, shape, seq_len)
+    oracle.set_bias(*[np.stack([m.read_weight(n, l) for l in range(2)]) for n in ("bq", "bk", "bv")])
+    m2 = host.Model(seq_len=seq_len, group_size=GS, qkv_bias=True, **shape)
+    m2.init_synthetic(13)
+    toks = np.random.default_rng(2).integers(0, 600, 530).astype(np.int32)
+    for pos, t in enumerate(toks):
+        want = oracle.forward(int(t), pos)
+        if pos < 5:
+            tol = 3e-5 * max(1.0, np.abs(want).max())
+            assert np.abs(m.step_logits(int(t), pos) - want).max() <= tol
+            assert np.abs(m2.forward_layers(int(t), pos) - want).max() <= tol
+    # batched prompt pass (fp16-activation GEMMs from 512 rows on): biases enter ahead of RoPE
+    last = m.prefill(toks)
+    assert np.abs(last - want).max() <= 4e-3 * np.abs(want).max()
+    ok_, ov_ = oracle.caches()
+    for layer in range(2):
+        k, v = m.read_kv(layer, len(toks))
+        assert np.abs(k - ok_[layer, :len(toks)]).max() <= 4e-3 * np.abs(ok_[layer]).max()
+        assert np.abs(v - ov_[layer, :len(toks)]).max() <= 4e-3 * np.abs(ov_[layer]).max()
+    # tensor-parallel ranks keep their heads' bias rows
+    for r in range(2):
+        mr = host.Model(seq_len=16, group_size=GS, tp_size=2, tp_rank=r, qkv_bias=True, **shape)
+        mr.init_synthetic(13)
+        np.testing.assert_array_equal(mr.read_weight("bq"), m.read_weight("bq")[r * 256:(r + 1) * 256])
+        np.testing.assert_array_equal(mr.read_weight("bv"), m.read_weight("bv")[r * 64:(r + 1) * 64])
+        mr.close()
+
+
+# ---------------- drop-in hazards ---------------------------------------------------------------------
+@pytest.mark.parametrize("H,KVH,hs,S,pos", [
+    (32, 8, 128, 4608, 4200),   # score tensor large enough to serve as the split workspace
+    (8, 2, 64, 128, 100),       # score tensor smaller than the ticket words: one split per kv head
+    (4, 2, 48, 96, 70),         # head size outside the tiled kernel: score rows used as such
+])
+def test_mha_layer_without_reserved_workspace_and_garbage_scores(H, KVH, hs, S, pos):
+    # a caller that never reserves the attention workspace hands over the reference's score tensor,
+    # un-zeroed (llama3.cpp:523-525): the layer must give the right answer anyway, twice in a row
+    rng = np.random.default_rng(pos)
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    got = host.mha_layer_no_workspace(q, kc, vc, H, H // KVH, hs, 0, pos)
+    want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    assert np.abs(got - want).max() <= 2e-5
+
+
+def test_row_parallel_layer_without_communicator_fails():
+    assert host.hlib().kxm_test_matmul_tp_without_comm() == 1
+    shape = dict(dim=512, hidden_dim=1024, layer_num=1, head_num=8, kv_head_num=2, vocab_size=256,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    m = host.Model(seq_len=16, group_size=GS, tp_size=2, tp_rank=0, **shape)
+    m.init_synthetic(5)
+    for step in (m.forward_layers, m.step_logits):   # neither init_comm nor a loopback group
+        with pytest.raises(kx.KxError):
+            step(1, 0)
+
+
 # ---------------- synthetic models vs the oracle ---------------------------------------------------
 def _oracle_from(m, cfg_kwargs, seq_len):
     c = kxo.Config(seq_len=seq_len, group_size=GS, **cfg_kwargs)
