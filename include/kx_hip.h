@@ -31,6 +31,7 @@ enum {
   KX_EINVAL = -1,      /* bad pointer / size / alignment */
   KX_EUNSUPPORTED = -2, /* shape outside what the kernels are built for */
   KX_EWORKSPACE = -3,  /* workspace too small */
+  KX_ELIMIT = -4,      /* input larger than the fixed capacity of an entry point that cannot allocate */
 };
 
 enum { KX_ROPE_INTERLEAVED = 0, KX_ROPE_HALF_SPLIT = 1 };
@@ -208,6 +209,21 @@ int kx_mha_decode_scores_f32(const float* query, const float* key_cache, const f
                              float* out, int32_t pos, int32_t head_num, int32_t kv_mul,
                              int32_t head_size, int32_t kv_dim, int32_t seq_len, int32_t layer_index,
                              float* score, size_t score_bytes, void* stream);
+
+/* kx_mha_decode_f32 for callers that cannot allocate device memory or hand over a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * in the reference.  The split workspace is a fixed array inside the library, one copy per GPU,
+ * of kx_mha_decode_static_limit_bytes() bytes (16 KiB + 128 x 64 x 132 floats = 4.14 MiB): calls
+ * whose kx_attn_workspace_bytes(head_num, head_size) -- or, for head sizes outside 32/64/128,
+ * 16 KiB + head_num*seq_len*4 -- exceed it return KX_ELIMIT.  The call clears the array's ticket
+ * words on `stream`, launches the same kernels as kx_mha_decode_f32 and gives the same result; it
+ * calls no allocator.  All calls on one GPU share the array: calls that overlap in time on one
+ * GPU (two streams) race. */
+size_t kx_mha_decode_static_limit_bytes(void);
+int kx_mha_decode_static_f32(const float* query, const float* key_cache, const float* value_cache,
+                             float* out, int32_t pos, int32_t head_num, int32_t kv_mul,
+                             int32_t head_size, int32_t kv_dim, int32_t seq_len, int32_t layer_index,
+                             void* stream);
 
 /* Same kernel with the position read from device memory (replayable under graph capture);
  * `max_pos` sizes the grid for the longest context this launch will ever see.  Needs a head

@@ -16,6 +16,8 @@
 // arrival ticket in the workspace) merges the split results, so one launch does it all.
 #include <math.h>
 
+#include <mutex>
+
 #include "kx_common.hpp"
 
 namespace kx {
@@ -684,6 +686,59 @@ extern "C" int kx_mha_decode_scores_f32(const float* query, const float* key_cac
   }
   return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
                                   head_size, kv_dim, seq_len, layer_index, nullptr, 0, stream);
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------
+// Split workspace of kx_mha_decode_static_f32: the ticket words followed by the split partials, as
+// in a caller-provided workspace.  One copy per GPU the library runs on, held until the process
+// ends.  Sized for 64 query heads of 128 (the largest model shape this library is benchmarked on,
+// unsharded): 16 KiB + 128 splits x 64 x 132 floats = 4.14 MiB.
+namespace kx {
+constexpr size_t kStaticPartialFloats = (size_t)kMaxSplits * 64 * (128 + 4);
+constexpr size_t kStaticScratchBytes = kTicketBytes + kStaticPartialFloats * sizeof(float);
+constexpr int kMaxDevices = 64;
+}  // namespace kx
+static __device__ __align__(256) unsigned char scratch[kx::kStaticScratchBytes];
+// Device address of `scratch` on each GPU (the array's name is only a host-side handle): looked up
+// once per device, with that device current.
+static void* g_scratch_ptr[kx::kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+extern "C" size_t kx_mha_decode_static_limit_bytes(void) { return kx::kStaticScratchBytes; }
+
+extern "C" int kx_mha_decode_static_f32(const float* query, const float* key_cache,
+                                        const float* value_cache, float* out, int32_t pos,
+                                        int32_t head_num, int32_t kv_mul, int32_t head_size,
+                                        int32_t kv_dim, int32_t seq_len, int32_t layer_index,
+                                        void* stream) {
+  using namespace kx;
+  if (head_num <= 0 || head_size <= 0 || seq_len <= 0) return KX_EINVAL;
+  const bool tiled = kv_mul > 0 && kv_mul <= 16 &&
+                     (head_size == 32 || head_size == 64 || head_size == 128);
+  // what the call would need of a caller-provided workspace must fit the static array
+  const size_t need = tiled ? kx_attn_workspace_bytes(head_num, head_size)
+                            : kTicketBytes + (size_t)head_num * (size_t)seq_len * sizeof(float);
+  if (need > kStaticScratchBytes) return KX_ELIMIT;
+  int dev = -1;
+  KX_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return KX_ELIMIT;
+  void* ptr = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+      void* p = nullptr;
+      KX_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+      if (!p) return KX_EINVAL;
+      g_scratch_ptr[dev] = p;
+    }
+    ptr = g_scratch_ptr[dev];
+  }
+  // The array keeps whatever the last call on this GPU left.  A launch that ran to completion
+  // returns its tickets to zero, one that was cut short does not: they are cleared every time.
+  KX_HIP_TRY(hipMemsetAsync(ptr, 0, kTicketBytes, (hipStream_t)stream));
+  return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
+                                  head_size, kv_dim, seq_len, layer_index, ptr, kStaticScratchBytes,
+                                  stream);
 }
 
 extern "C" int kx_mha_decode_dpos_f32(const float* query, const float* key_cache,

@@ -12,6 +12,7 @@ extern "C" const char* kx_error_string(int code) {
     case KX_EINVAL: return "kx: invalid argument";
     case KX_EUNSUPPORTED: return "kx: unsupported shape";
     case KX_EWORKSPACE: return "kx: workspace too small";
+    case KX_ELIMIT: return "kx: input exceeds the fixed scratch capacity of this entry point";
     default: break;
   }
   if (code >= 10000) return "kx: RCCL call failed (code - 10000 is the ncclResult_t)";

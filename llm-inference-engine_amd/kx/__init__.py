@@ -78,6 +78,9 @@ SIGNATURES = {
                                     _vp, _sz, _vp]),
     "kx_mha_decode_scores_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                            _i32, _vp, _sz, _vp]),
+    "kx_mha_decode_static_limit_bytes": (_sz, []),
+    "kx_mha_decode_static_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                           _i32, _vp]),
     "kx_mha_decode_dpos_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                          _i32, _i32, _vp, _sz, _vp]),
     "kx_flash_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
