@@ -116,6 +116,20 @@ SIGNATURES = {
 }
 
 
+class GemvDesc(C.Structure):
+    """kx_gemv_w8_desc of include/kx_hip.h, field for field."""
+    _fields_ = [("mode", C.c_int32), ("group_size", C.c_int32), ("M", C.c_int32), ("K", C.c_int32),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("scales", C.c_void_p), ("norm_w", C.c_void_p),
+                ("norm_eps", C.c_float), ("y0", C.c_void_p), ("y1", C.c_void_p), ("y2", C.c_void_p),
+                ("k0", C.c_int32), ("k1", C.c_int32), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("sin_cache", C.c_void_p), ("cos_cache", C.c_void_p), ("pos_dev", C.c_void_p),
+                ("pos", C.c_int32), ("rope_variant", C.c_int32), ("head_size", C.c_int32),
+                ("kv_pos_stride", C.c_int32), ("kv_f16", C.c_int32)]
+
+
+GEMV_PLAIN, GEMV_GATE_UP, GEMV_QKV_ROPE = 0, 1, 2
+
+
 def lib():
     """Loads libkx_hip.so; raises KxError (never falls back) when it is absent."""
     global _lib

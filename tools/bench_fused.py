@@ -12,14 +12,7 @@ import kx  # noqa: E402
 GS = 64
 
 
-class Desc(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("group_size", C.c_int32), ("M", C.c_int32), ("K", C.c_int32),
-                ("x", C.c_void_p), ("w", C.c_void_p), ("scales", C.c_void_p), ("norm_w", C.c_void_p),
-                ("norm_eps", C.c_float), ("y0", C.c_void_p), ("y1", C.c_void_p), ("y2", C.c_void_p),
-                ("k0", C.c_int32), ("k1", C.c_int32), ("bias", C.c_void_p), ("residual", C.c_void_p),
-                ("sin_cache", C.c_void_p), ("cos_cache", C.c_void_p), ("pos_dev", C.c_void_p),
-                ("pos", C.c_int32), ("rope_variant", C.c_int32), ("head_size", C.c_int32),
-                ("kv_pos_stride", C.c_int32)]
+Desc = kx.GemvDesc
 
 
 def main():
