@@ -130,6 +130,21 @@ typedef struct kx_gemv_w8_desc {
 } kx_gemv_w8_desc;
 int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* desc, void* stream);
 
+/* Up to four dependent fused GEMVs (descs[i+1] may read anything descs[0..i] write: the Wo ->
+ * W1|W3 -> W2 -> next layer's Wq|Wk|Wv chain of a decode step) in ONE launch; same results as
+ * n calls of kx_gemv_w8_fused_f32 up to summation order.  No reference counterpart (the reference
+ * launches every matmul separately, llama3.cpp:648-788).  One workgroup per CU walks the stages;
+ * the weights of a stage are requested before the grid-wide barrier that guards its input, so the
+ * memory pipeline stays full across the seam.  `state` (kx_gemv_chain_state_bytes() bytes, 256-byte
+ * aligned) holds the barrier words: ZERO IT ONCE, then pass the same buffer to every call on this
+ * device; calls sharing a state buffer must not overlap in time.  Word state[kx_gemv_chain_state_bytes()/4 - 64]
+ * turns non-zero if a barrier ever gave up waiting (tens of ms): results of that call are then
+ * invalid and the buffer must be zeroed again.  Needs the fast-path preconditions of
+ * kx_gemv_w8_f32 for every stage (else KX_EUNSUPPORTED). */
+size_t kx_gemv_chain_state_bytes(void);
+int kx_gemv_w8_chain_f32(const kx_gemv_w8_desc* descs, int32_t n, void* state, size_t state_bytes,
+                         void* stream);
+
 /* ---------------- fp32 GEMV ----------------
  * Replaces matmul_kernel_cu / matmul_kernel_cu_fp32 (cuda/matmul_kernel.cu:6-54,89-109) and
  * matmul_kernel_cpu (cpu/matmul_kernel.cpp:5-41) behind MatmulKernel (kernels_interface.h:9-10):

@@ -24,6 +24,7 @@
 // Rounding order differs from the reference only in where the scale is applied: the 16
 // products x*w of a lane are summed first and the group scale multiplies that partial sum.
 #include <algorithm>
+#include <cstdlib>
 #include "gemv_w8.hpp"
 
 namespace kx {
@@ -79,6 +80,11 @@ __device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, flo
   }
 }
 
+__device__ __forceinline__ void store_out(const GemvW8Args& a, float* p, float v) {
+  if (a.coherent_out) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
 // Row of the stacked q|k|v product -> its destination; k and v rows go to the position's cache row,
 // rounded to fp16 when the cache holds fp16.
 __device__ __forceinline__ void store_routed(const GemvW8Args& a, int row, int pos, float v) {
@@ -91,7 +97,7 @@ __device__ __forceinline__ void store_routed(const GemvW8Args& a, int row, int p
   float* dst;
   int rr;
   route(a, row, pos, dst, rr);
-  dst[rr] = v;
+  store_out(a, dst + rr, v);
 }
 
 // Issues the 128-bit weight loads (and the one scale per load) of U chunks of R rows.
@@ -138,32 +144,36 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
 // weights stay in flight across the LDS writes, the barrier and the norm reduction.  Requested
 // behind the weights, x could not be touched before every weight of the batch had arrived.
 constexpr int kXPer = 4;  // loads per thread and pass, all requested before the first is used
-struct GemvXRegs {
-  f32x4 v[kXPer];
-  f32x4 g[kXPer];
+template <int XP>
+struct GemvXRegsT {
+  f32x4 v[XP];
+  f32x4 g[XP];
 };
+using GemvXRegs = GemvXRegsT<kXPer>;
 
 // Unconditional loads with a clamped index: a load under a test would be waited for on its own.
-__device__ __forceinline__ void request_x(const GemvW8Args& a, int i0, GemvXRegs& X) {
+template <int XP>
+__device__ __forceinline__ void request_x(const GemvW8Args& a, int i0, GemvXRegsT<XP>& X) {
   const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
   const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
   const int m4 = a.M >> 2, bd = blockDim.x;
 #pragma unroll
-  for (int j = 0; j < kXPer; ++j) {
+  for (int j = 0; j < XP; ++j) {
     const int idx = min(i0 + j * bd, m4 - 1);
     X.v[j] = xg[idx];
     if (a.norm_w) X.g[j] = ng[idx];
   }
 }
 
-// One pass of staging: the kXPer vectors of X (requested for pass start i0) go to LDS; returns
+// One pass of staging: the vectors of X (requested for pass start i0) go to LDS; returns
 // their sum of squares.
+template <int XP>
 __device__ __forceinline__ float stage_pass(const GemvW8Args& a, f32x4* xs, int i0, bool norm,
-                                            const GemvXRegs& X) {
+                                            const GemvXRegsT<XP>& X) {
   const int n4 = a.chunks * 256, m4 = a.M >> 2, bd = blockDim.x;
   float ss = 0.f;
 #pragma unroll
-  for (int j = 0; j < kXPer; ++j) {
+  for (int j = 0; j < XP; ++j) {
     const int i = i0 + j * bd;
     if (i < n4) {
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -182,13 +192,15 @@ __device__ __forceinline__ float stage_pass(const GemvW8Args& a, f32x4* xs, int 
 // Ends with one workgroup barrier.  The first pass (requested ahead of the weights) is straight-
 // line code of its own: sharing a loop body with the later passes, whose loads are the youngest
 // in flight, it would inherit their wait and sit until the weights had arrived too.
-__device__ __forceinline__ float commit_x(const GemvW8Args& a, f32x4* xs, float* red, GemvXRegs& X) {
+template <int XP>
+__device__ __forceinline__ float commit_x(const GemvW8Args& a, f32x4* xs, float* red,
+                                          GemvXRegsT<XP>& X) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwaves = blockDim.x >> 6, bd = blockDim.x;
   const int n4 = a.chunks * 256;
   const bool norm = a.norm_w != nullptr;
   float ss = stage_pass(a, xs, tid, norm, X);
-  for (int i0 = tid + kXPer * bd; i0 < n4; i0 += kXPer * bd) {
+  for (int i0 = tid + XP * bd; i0 < n4; i0 += XP * bd) {
     request_x(a, i0, X);
     ss += stage_pass(a, xs, i0, norm, X);
   }
@@ -326,7 +338,7 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
         float* dst;
         int rr;
         route(a, row, 0, dst, rr);
-        dst[rr] = S.total[r] + (S.bias[r] + S.residual[r]);
+        store_out(a, dst + rr, S.total[r] + (S.bias[r] + S.residual[r]));
       }
     }
   }
@@ -439,6 +451,169 @@ __global__ void gemv_w8_generic_kernel(const GemvW8Args a, int32_t group_size) {
   }
 }
 
+// ---- several dependent GEMVs in one launch -------------------------------------------------
+// A decode layer is a chain of matrix-vector products, each consuming the previous one's whole
+// output: as separate launches every link pays the kernel boundary and the ramp of a cold memory
+// pipeline.  But a GEMV's weights do not depend on its input vector: here one grid (one 16-wave
+// workgroup per CU, all resident) walks the chain, and before it waits at the grid barrier that
+// guards stage n+1's input each wave has already requested its first batch of stage n+1's weights,
+// so HBM keeps streaming across the seam.  Stage outputs leave as write-through device-scope
+// stores; the barrier is a release/acquire pair at device scope.
+//
+// Barrier state (zeroed once by the owner, then reused by every launch of the SAME grid size):
+// the workgroups form kChainGroups groups by blockIdx % 8 (round-robin placement puts a group on
+// one XCD: a speed matter only).  Arrivals count up on the group's word; the group's last arriver
+// counts up the top word, waits for all groups, and publishes the group's generation, on which
+// the rest of the group polls.  Counters only grow (compared modulo 2^32), so nothing is reset.
+// Every spin is bounded: on giving up a workgroup raises the error word and runs on, so the grid
+// always drains.
+constexpr int kChainGroups = 8;
+constexpr int kChainWordStride = 64;  // 256 bytes between the words
+constexpr int kChainErrWord = (2 * kChainGroups + 1) * kChainWordStride;
+constexpr size_t kChainStateBytes = (2 * kChainGroups + 2) * kChainWordStride * sizeof(unsigned);
+constexpr int kChainMaxStages = 4;
+constexpr int kChainThreads = 1024;
+constexpr unsigned kChainSpinLimit = 1u << 18;  // polls of ~1 us each: a quarter of a second
+
+struct GemvChainArgs {
+  GemvW8Args st[kChainMaxStages];
+  int32_t mode[kChainMaxStages];
+  int32_t n;
+  unsigned* bar;
+  // optional timeline (tools/bench_chain.py): 16 wall-clock stamps (100 MHz) per workgroup
+  unsigned long long* trace;
+};
+constexpr int kChainTraceSlots = 16;
+
+__device__ __forceinline__ void chain_stamp(unsigned long long* trace, int slot) {
+  if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * kChainTraceSlots + slot] = wall_clock64();
+}
+
+__device__ __forceinline__ unsigned chain_ld(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct ChainBarrier {
+  unsigned* cnt;   // this group's arrival counter
+  unsigned* genw;  // this group's published generation
+  unsigned* top;
+  unsigned* err;
+  unsigned gen, group_size, ngroups;
+
+  __device__ void init(unsigned* base) {
+    const unsigned grid = gridDim.x, g = blockIdx.x % kChainGroups;
+    ngroups = grid < (unsigned)kChainGroups ? grid : (unsigned)kChainGroups;
+    group_size = (grid - g + kChainGroups - 1) / kChainGroups;
+    cnt = base + g * kChainWordStride;
+    genw = base + (kChainGroups + g) * kChainWordStride;
+    top = base + 2 * kChainGroups * kChainWordStride;
+    err = base + kChainErrWord;
+    // stable for the whole group until every one of its workgroups has arrived at a barrier
+    gen = chain_ld(genw);
+  }
+
+  // All workgroups of the grid meet here.  Stores issued before it (write-through) are visible
+  // to every load issued after it.
+  __device__ void sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
+    __syncthreads();
+    ++gen;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      if (old + 1u == group_size * gen) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(chain_ld(top) - ngroups * gen) < 0 && ++spins < kChainSpinLimit)
+          __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        __hip_atomic_store(genw, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while ((int)(chain_ld(genw) - gen) < 0 && ++spins < kChainSpinLimit)
+          __builtin_amdgcn_s_sleep(1);
+      }
+      if (spins >= kChainSpinLimit)
+        __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // One cache invalidate per workgroup: the vector cache it acts on belongs to the CU, and the
+    // workgroup barrier below orders it ahead of every other wave's loads.  (Issued by all 16
+    // waves of all workgroups it cost ~40 us per barrier.)
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+  }
+};
+
+// One stage on this workgroup's share of the rows.  `wait` = the stage reads what an earlier
+// stage of this launch wrote: the first weight batch is requested, THEN the grid meets, then x is
+// staged (epilogue operands too: a residual may be an earlier stage's output).
+template <int R, int U, int MODE>
+__device__ __forceinline__ void chain_stage(const GemvW8Args& a, f32x4* xs, float* red,
+                                            ChainBarrier& bar, bool wait,
+                                            unsigned long long* trace, int slot0) {
+  constexpr bool GU = MODE == GEMV_GATE_UP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int out_rows = GU ? a.swiglu_half : a.K;
+  const int row_begin = blockIdx.x * a.rows_per_block;
+  const int row_end = min(row_begin + a.rows_per_block, out_rows);
+  const int col_lane = lane * 16;
+  int r0 = row_begin + wave * R;
+  const bool have = r0 < row_end;
+
+  GemvBatch<R, U, GU> B;
+  GemvRows<R, GU> S;
+  if (have) {
+    begin_rows<R, MODE>(S);
+    load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, 0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
+  }
+  chain_stamp(trace, slot0);
+  if (wait) bar.sync();
+  chain_stamp(trace, slot0 + 1);
+  // 16 waves stage x: one or two vectors a thread cover up to 8 chunks in a single pass
+  GemvXRegsT<2> X;
+  request_x(a, threadIdx.x, X);
+  const float rs = commit_x(a, xs, red, X);
+  chain_stamp(trace, slot0 + 2);
+  if (!have) return;
+  int pos = 0;
+  if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
+  request_epilogue<R, MODE>(a, r0, row_end, pos, S);
+  consume<R, U, MODE>(a, xs, lane, 0, B, S);
+  for (int c0 = U; c0 < a.chunks; c0 += U) {
+    load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
+    consume<R, U, MODE>(a, xs, lane, c0, B, S);
+  }
+  finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
+  for (r0 += nwaves * R; r0 < row_end; r0 += nwaves * R) {
+    begin_rows<R, MODE>(S);
+    request_epilogue<R, MODE>(a, r0, row_end, pos, S);
+    for (int c0 = 0; c0 < a.chunks; c0 += U) {
+      load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
+      consume<R, U, MODE>(a, xs, lane, c0, B, S);
+    }
+    finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
+  }
+}
+
+__global__ __launch_bounds__(kChainThreads) void gemv_chain_kernel(const GemvChainArgs c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* xs = reinterpret_cast<f32x4*>(smem);
+  __shared__ float red[16];
+  ChainBarrier bar;
+  bar.init(c.bar);
+#pragma unroll
+  for (int i = 0; i < kChainMaxStages; ++i) {
+    if (i >= c.n) break;
+    const GemvW8Args& a = c.st[i];
+    switch (c.mode[i]) {
+      case GEMV_GATE_UP: chain_stage<1, 2, GEMV_GATE_UP>(a, xs, red, bar, i > 0, c.trace, 3 * i); break;
+      case GEMV_QKV_ROPE: chain_stage<2, 2, GEMV_QKV_ROPE>(a, xs, red, bar, i > 0, c.trace, 3 * i); break;
+      default: chain_stage<1, 4, GEMV_PLAIN>(a, xs, red, bar, i > 0, c.trace, 3 * i); break;
+    }
+  }
+  chain_stamp(c.trace, 3 * kChainMaxStages);
+}
+
 template <int R, int U, int MODE>
 static int launch(const GemvW8Args& a, int threads, hipStream_t s) {
   const int out_rows = MODE == GEMV_GATE_UP ? a.swiglu_half : a.K;
@@ -463,16 +638,24 @@ static int ilog2(int v) {
   return s;
 }
 
-int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) {
+// Argument checks shared by the single-launch and the chained form; *fast = the 16-byte-chunk
+// kernels apply.
+static int gemv_w8_check(const GemvW8Args& a, int32_t group_size, bool* fast) {
   if (!a.x || !a.w || !a.scales || !a.y0) return KX_EINVAL;
   if (a.M <= 0 || a.K <= 0 || group_size <= 0) return KX_EINVAL;
   if (a.M % 4 != 0) return KX_EINVAL;  // matmul_kernel.cu:123
   if (((size_t)a.M * (size_t)a.K) % (size_t)group_size != 0) return KX_EINVAL;
   const bool pow2 = (group_size & (group_size - 1)) == 0;
-  const bool fast = pow2 && group_size % 16 == 0 && a.M % group_size == 0 && a.M % 16 == 0 &&
-                    ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&
-                    (!a.norm_w || (uintptr_t)a.norm_w % 16 == 0) &&
-                    (size_t)((a.M + 1023) / 1024) * 4096 <= 160 * 1024 - 64;
+  *fast = pow2 && group_size % 16 == 0 && a.M % group_size == 0 && a.M % 16 == 0 &&
+          ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&
+          (!a.norm_w || (uintptr_t)a.norm_w % 16 == 0) &&
+          (size_t)((a.M + 1023) / 1024) * 4096 <= 160 * 1024 - 64;
+  return KX_OK;
+}
+
+int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) {
+  bool fast = false;
+  if (int rc = gemv_w8_check(a, group_size, &fast)) return rc;
   if (!fast) {
     if (mode != GEMV_PLAIN || a.norm_w) return KX_EUNSUPPORTED;
     const int wpb = 4;
@@ -566,9 +749,74 @@ extern "C" int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const fl
   return kx::gemv_w8_dispatch(a, group_size, kx::GEMV_GATE_UP, (hipStream_t)stream);
 }
 
+static int args_from_desc(const kx_gemv_w8_desc* d, kx::GemvW8Args& a);
+
 extern "C" int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* d, void* stream) {
   if (!d) return KX_EINVAL;
   kx::GemvW8Args a{};
+  if (int rc = args_from_desc(d, a)) return rc;
+  return kx::gemv_w8_dispatch(a, d->group_size, d->mode, (hipStream_t)stream);
+}
+
+extern "C" size_t kx_gemv_chain_state_bytes(void) { return kx::kChainStateBytes; }
+
+extern "C" int kx_gemv_w8_chain_f32(const kx_gemv_w8_desc* descs, int32_t n, void* state,
+                                    size_t state_bytes, void* stream) {
+  using namespace kx;
+  if (!descs || n < 1 || n > kChainMaxStages) return KX_EINVAL;
+  if (!state || state_bytes < kChainStateBytes || (uintptr_t)state % 256) return KX_EWORKSPACE;
+  // one workgroup per CU: every workgroup is resident, so the in-launch barriers complete
+  static int cus_of[64];
+  int dev = 0;
+  KX_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return KX_EUNSUPPORTED;
+  if (!cus_of[dev]) {
+    int cus = 0;
+    KX_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) return KX_EUNSUPPORTED;
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_chain_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    int per_cu = 0;
+    KX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, reinterpret_cast<const void*>(&gemv_chain_kernel), kChainThreads, 160 * 1024 - 64));
+    if (per_cu < 1) return KX_EUNSUPPORTED;
+    cus_of[dev] = cus;
+  }
+  const int grid = cus_of[dev];
+  GemvChainArgs c{};
+  c.n = n;
+  c.bar = static_cast<unsigned*>(state);
+  // a state buffer with room for it, and KX_CHAIN_TRACE set: per-workgroup timeline behind the words
+  if (state_bytes >= kChainStateBytes + (size_t)grid * kChainTraceSlots * 8 && getenv("KX_CHAIN_TRACE"))
+    c.trace = reinterpret_cast<unsigned long long*>(static_cast<char*>(state) + kChainStateBytes);
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const kx_gemv_w8_desc* d = descs + i;
+    GemvW8Args& a = c.st[i];
+    if (int rc = args_from_desc(d, a)) return rc;
+    bool fast = false;
+    if (int rc = gemv_w8_check(a, d->group_size, &fast)) return rc;
+    if (!fast) return KX_EUNSUPPORTED;
+    a.chunks = (a.M + 1023) / 1024;
+    a.gs_shift = ilog2(d->group_size);
+    a.groups_per_row = a.M / d->group_size;
+    a.coherent_out = i + 1 < n;
+    c.mode[i] = d->mode;
+    if (d->mode == GEMV_QKV_ROPE && (a.K % 2 || a.k0 % 2 || a.k1 % 2 || a.head_size % 2))
+      return KX_EINVAL;
+    const int out_rows = d->mode == GEMV_GATE_UP ? a.swiglu_half : a.K;
+    const int R = d->mode == GEMV_QKV_ROPE ? 2 : 1;
+    int rpb = (out_rows + grid - 1) / grid;
+    rpb = ((rpb + R - 1) / R) * R;
+    a.rows_per_block = rpb;
+    lds = std::max(lds, (size_t)a.chunks * 4096);
+  }
+  hipLaunchKernelGGL(gemv_chain_kernel, dim3(grid), dim3(kChainThreads), lds, (hipStream_t)stream, c);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+static int args_from_desc(const kx_gemv_w8_desc* d, kx::GemvW8Args& a) {
   a.x = d->x; a.w = d->w; a.scales = d->scales;
   a.norm_w = d->norm_w; a.norm_eps = d->norm_eps;
   a.M = d->M; a.K = d->K;
@@ -601,5 +849,5 @@ extern "C" int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* d, void* stream) {
   }
   if (k0 < 0 || k1 < k0 || k1 > d->K) return KX_EINVAL;
   a.k0 = k0; a.k1 = k1;
-  return kx::gemv_w8_dispatch(a, d->group_size, d->mode, (hipStream_t)stream);
+  return KX_OK;
 }

@@ -135,6 +135,75 @@ def test_gemv_w8_full_size_linearity():
         assert abs(y1[r] - want) <= 1e-5 * w8_abs_sum(x1, w[r:r + 1], s[r * M // GS:(r + 1) * M // GS])
 
 
+# ------------------------------- chained GEMVs in one launch ------------------------------------
+def _chain_case(dim, hid, H, KVH, hs, n_stages, seed):
+    """Wo(+residual) -> RMSNorm+W1|W3+SwiGLU -> W2(+residual) -> RMSNorm+Wq|Wk|Wv+RoPE+cache row,
+    every stage reading the previous one's output, with the oracle's answer for each buffer."""
+    rng = np.random.default_rng(seed)
+    kvd, S, pos = KVH * hs, 48, 33
+    qkv_rows = H * hs + 2 * kvd
+    mats = {n: rand_w8(rng, K, M)[1:] for n, (K, M) in
+            dict(wo=(dim, H * hs), w13=(2 * hid, dim), w2=(dim, hid), qkv=(qkv_rows, dim)).items()}
+    for n in mats:
+        mats[n] = (mats[n][0], mats[n][1] * 8)
+    att = rng.standard_normal(H * hs).astype(np.float32)
+    x0 = rng.standard_normal(dim).astype(np.float32)
+    g1 = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+    g2 = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+    sin, cos = kxo.sin_cos_cache(hs, S, 5e5)
+    # oracle
+    x1 = x0 + kxo.gemv_w8(att, *mats["wo"], GS, threads=8)
+    full = kxo.gemv_w8(kxo.rmsnorm(x1, g1, 1e-5), *mats["w13"], GS, threads=8)
+    h = kxo.swiglu(full[:hid], full[hid:])
+    x2 = x1 + kxo.gemv_w8(h, *mats["w2"], GS, threads=8)
+    qkv = kxo.gemv_w8(kxo.rmsnorm(x2, g2, 1e-5), *mats["qkv"], GS, threads=8)
+    q, k = kxo.rope(1, H * hs, kvd, hs, qkv[:H * hs], qkv[H * hs:H * hs + kvd], pos, sin, cos)
+    want = dict(x1=x1, h=h, x2=x2, q=q, k=k, v=qkv[H * hs + kvd:])
+    dev = {n: (kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)) for n, (w, s) in mats.items()}
+    b = dict(att=kx.Buf.from_numpy(att), x=kx.Buf.from_numpy(x0), h=kx.Buf.zeros(hid),
+             q=kx.Buf.zeros(H * hs), kc=kx.Buf.zeros((S, kvd)), vc=kx.Buf.zeros((S, kvd)),
+             g1=kx.Buf.from_numpy(g1), g2=kx.Buf.from_numpy(g2), sin=kx.Buf.from_numpy(sin),
+             cos=kx.Buf.from_numpy(cos), pos=kx.Buf.from_numpy(np.array([pos], np.int32)))
+    D = kx.GemvDesc
+    descs = (D * 4)(
+        D(mode=0, group_size=GS, M=H * hs, K=dim, x=b["att"].ptr, w=dev["wo"][0].ptr,
+          scales=dev["wo"][1].ptr, y0=b["x"].ptr, residual=b["x"].ptr),
+        D(mode=1, group_size=GS, M=dim, K=2 * hid, x=b["x"].ptr, w=dev["w13"][0].ptr,
+          scales=dev["w13"][1].ptr, norm_w=b["g1"].ptr, norm_eps=1e-5, y0=b["h"].ptr),
+        D(mode=0, group_size=GS, M=hid, K=dim, x=b["h"].ptr, w=dev["w2"][0].ptr,
+          scales=dev["w2"][1].ptr, y0=b["x"].ptr, residual=b["x"].ptr),
+        D(mode=2, group_size=GS, M=dim, K=qkv_rows, x=b["x"].ptr, w=dev["qkv"][0].ptr,
+          scales=dev["qkv"][1].ptr, norm_w=b["g2"].ptr, norm_eps=1e-5, y0=b["q"].ptr, y1=b["kc"].ptr,
+          y2=b["vc"].ptr, k0=H * hs, k1=H * hs + kvd, sin_cache=b["sin"].ptr, cos_cache=b["cos"].ptr,
+          pos_dev=b["pos"].ptr, rope_variant=1, head_size=hs, kv_pos_stride=kvd))
+    return descs, b, dev, want, pos
+
+
+@pytest.mark.parametrize("dim,hid,H,KVH,hs", [(256, 512, 4, 2, 64), (1024, 2816, 8, 2, 128),
+                                              (4096, 14336, 32, 8, 128), (2048, 8192, 32, 8, 64),
+                                              (3584, 4736, 7, 1, 128)])
+def test_gemv_chain_one_launch_vs_oracle_and_separate_launches(dim, hid, H, KVH, hs):
+    L = kx.lib()
+    state = kx.Buf.zeros(L.kx_gemv_chain_state_bytes(), np.uint8)
+    for n_stages in (4, 3, 1, 2, 4):   # one state buffer across launches of different lengths
+        descs, b, dev, want, pos = _chain_case(dim, hid, H, KVH, hs, n_stages, seed=dim + n_stages)
+        kx.check(L.kx_gemv_w8_chain_f32(descs, n_stages, state.ptr, state.nbytes, None), "chain")
+        for i in range(n_stages, 4):
+            kx.check(L.kx_gemv_w8_fused_f32(C.byref(descs[i]), None))
+        kx.sync()
+        got = dict(x2=b["x"].numpy(), h=b["h"].numpy(), q=b["q"].numpy(), k=b["kc"].numpy()[pos],
+                   v=b["vc"].numpy()[pos])
+        for name in ("h", "x2", "q", "k", "v"):
+            scale = np.abs(want[name]).max()
+            assert np.abs(got[name] - want[name]).max() <= 3e-5 * scale, (name, n_stages)
+        words = state.numpy(np.uint32, (state.nbytes // 4,))
+        assert words[-64] == 0, "a grid barrier gave up"
+    # preconditions: stage count, state buffer, shapes outside the 16-byte-chunk kernels
+    assert L.kx_gemv_w8_chain_f32(descs, 5, state.ptr, state.nbytes, None) == -1
+    assert L.kx_gemv_w8_chain_f32(descs, 2, None, 0, None) == -3
+    assert L.kx_gemv_w8_chain_f32(descs, 2, state.ptr, 64, None) == -3
+
+
 # ------------------------------- fp32 GEMV ---------------------------------------------------
 def test_gemv_f32_reference_known_answers():
     # test/test_op/test_cu_matmul.cpp:48-106
