@@ -76,6 +76,8 @@ SIGNATURES = {
     "kx_flash_attention_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _sz, _vp]),
+    "kx_mha_decode_wo_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32,
+                                       _i32, _vp, _vp, _sz, _vp]),
     "kx_mha_decode_scores_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                            _i32, _vp, _sz, _vp]),
     "kx_mha_decode_static_limit_bytes": (_sz, []),

@@ -361,6 +361,57 @@ def test_mha_decode_device_position_one_workspace_many_launches():
     assert not ws.numpy(np.uint8, (wsb,))[:16384].any()  # tickets are back at zero
 
 
+@pytest.mark.parametrize("H,KVH,hs,S,dim", [(32, 8, 128, 4736, 4096), (32, 8, 64, 700, 2048),
+                                             (28, 4, 128, 600, 3584), (8, 1, 128, 4400, 8192),
+                                             (12, 12, 64, 300, 768), (4, 2, 128, 96, 256)])
+def test_mha_decode_with_fused_output_projection(H, KVH, hs, S, dim):
+    # attention + Wo (+ residual) in one launch against the oracle's mha -> gemv_w8 -> add, at
+    # positions with one split, a few splits and the full grid; position by value and on the device;
+    # one workspace for all launches (its finished-heads counter only ever counts up)
+    rng = np.random.default_rng(H * 1000 + S)
+    kvd, M = KVH * hs, H * hs
+    kc = rng.standard_normal((2, S, kvd)).astype(np.float32)
+    vc = rng.standard_normal((2, S, kvd)).astype(np.float32)
+    _, w, s = rand_w8(rng, dim, M)
+    s *= 30
+    L = kx.lib()
+    dk, dv, dw, dsc = map(kx.Buf.from_numpy, (kc, vc, w, s))
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    att, y = kx.Buf.zeros(M), kx.Buf.zeros(dim)
+    pos_dev = kx.Buf.zeros(1, np.int32)
+    for i, pos in enumerate((0, 17, 63, 64, 300, S - 1, 5, S // 2)):
+        if pos >= S:
+            continue
+        q = rng.standard_normal(M).astype(np.float32)
+        res = rng.standard_normal(dim).astype(np.float32)
+        dq = kx.Buf.from_numpy(q)
+        y.upload(res)
+        d = kx.GemvDesc(mode=kx.GEMV_PLAIN, group_size=GS, M=M, K=dim, x=att.ptr, w=dw.ptr,
+                        scales=dsc.ptr, y0=y.ptr, residual=y.ptr)
+        on_device = i % 2 == 1
+        pos_dev.upload(np.array([pos], np.int32))
+        kx.check(L.kx_mha_decode_wo_f32(dq.ptr, dk.ptr, dv.ptr, att.ptr, S - 1 if on_device else pos,
+                                        pos_dev.ptr if on_device else None, H, H // KVH, hs, kvd, S, 1,
+                                        C.byref(d), ws.ptr, wsb, None), "kx_mha_decode_wo_f32")
+        kx.sync()
+        want_att = kxo.mha(pos, H, 1, S, kvd, H // KVH, hs, q, kc, vc)
+        np.testing.assert_allclose(att.numpy(), want_att, rtol=0, atol=2e-5, err_msg=f"pos={pos}")
+        want_y = res + kxo.gemv_w8(want_att, w, s, GS, threads=8)
+        tol = 1e-5 * w8_abs_sum(want_att, w, s) + 2e-5 * w8_abs_sum(np.ones_like(want_att), w, s) + 1e-6
+        assert np.all(np.abs(y.numpy() - want_y) <= tol), f"pos={pos}"
+    words = ws.numpy(np.uint8, (wsb,))[:16384].view(np.uint32)
+    assert words[62 * 64] == 0, "a wait for the attention output gave up"
+    assert not words[:KVH * 64].any()     # split tickets are back at zero
+    # preconditions: the projection must read the attention output, plain mode, no norm
+    bad = kx.GemvDesc(mode=kx.GEMV_PLAIN, group_size=GS, M=M, K=dim, x=y.ptr, w=dw.ptr, scales=dsc.ptr,
+                      y0=y.ptr)
+    assert L.kx_mha_decode_wo_f32(dq.ptr, dk.ptr, dv.ptr, att.ptr, 3, None, H, H // KVH, hs, kvd, S, 1,
+                                  C.byref(bad), ws.ptr, wsb, None) == -1
+    assert L.kx_mha_decode_wo_f32(dq.ptr, dk.ptr, dv.ptr, att.ptr, 3, None, H, H // KVH, hs, kvd, S, 1,
+                                  C.byref(d), ws.ptr, 20000, None) == -3
+
+
 def test_mha_decode_forced_rescale_and_no_workspace():
     # one key far above the rest late in the sequence forces the online-softmax rescale branch;
     # with no workspace the kernel must fall back to a single split and still be right
