@@ -130,21 +130,6 @@ typedef struct kx_gemv_w8_desc {
 } kx_gemv_w8_desc;
 int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* desc, void* stream);
 
-/* Up to four dependent fused GEMVs (descs[i+1] may read anything descs[0..i] write: the Wo ->
- * W1|W3 -> W2 -> next layer's Wq|Wk|Wv chain of a decode step) in ONE launch; same results as
- * n calls of kx_gemv_w8_fused_f32 up to summation order.  No reference counterpart (the reference
- * launches every matmul separately, llama3.cpp:648-788).  One workgroup per CU walks the stages;
- * the weights of a stage are requested before the grid-wide barrier that guards its input, so the
- * memory pipeline stays full across the seam.  `state` (kx_gemv_chain_state_bytes() bytes, 256-byte
- * aligned) holds the barrier words: ZERO IT ONCE, then pass the same buffer to every call on this
- * device; calls sharing a state buffer must not overlap in time.  Word state[kx_gemv_chain_state_bytes()/4 - 64]
- * turns non-zero if a barrier ever gave up waiting (tens of ms): results of that call are then
- * invalid and the buffer must be zeroed again.  Needs the fast-path preconditions of
- * kx_gemv_w8_f32 for every stage (else KX_EUNSUPPORTED). */
-size_t kx_gemv_chain_state_bytes(void);
-int kx_gemv_w8_chain_f32(const kx_gemv_w8_desc* descs, int32_t n, void* state, size_t state_bytes,
-                         void* stream);
-
 /* ---------------- fp32 GEMV ----------------
  * Replaces matmul_kernel_cu / matmul_kernel_cu_fp32 (cuda/matmul_kernel.cu:6-54,89-109) and
  * matmul_kernel_cpu (cpu/matmul_kernel.cpp:5-41) behind MatmulKernel (kernels_interface.h:9-10):
@@ -212,24 +197,6 @@ int kx_mha_decode_f32(const float* query, const float* key_cache, const float* v
                       float* out, int32_t pos, int32_t head_num, int32_t kv_mul, int32_t head_size,
                       int32_t kv_dim, int32_t seq_len, int32_t layer_index, void* workspace,
                       size_t workspace_bytes, void* stream);
-
-/* Attention followed by the output projection in ONE launch (MultiHeadAttention::forward then
- * wo_layer->forward, llama3.cpp:716-743, residual add of :751-752 included when wo->residual is
- * set).  `wo` describes the projection as for kx_gemv_w8_fused_f32: mode KX_GEMV_PLAIN, x == att_out
- * (the attention output still lands there), M == head_num*head_size, y0 (+ optional residual /
- * bias), no norm, no routing.  While the split partials of the attention travel to the workgroups
- * that merge them, every workgroup requests its share of the projection's weights; a counter of
- * finished kv heads in the workspace releases the projection.  Same results as kx_mha_decode_f32 /
- * _dpos_f32 followed by kx_gemv_w8_fused_f32, up to summation order.  pos_dev non-null: position
- * read on the device, `pos` = the largest position the launch may see.  Needs head size 64 or
- * 128, an fp32 cache, kx_attn_workspace_bytes() of zeroed workspace (its ticket area also holds
- * the counter and an error word: word 62*64 of the workspace turns non-zero if a wait ever gave
- * up), and a grid that is resident at once (else KX_EUNSUPPORTED: use the two separate calls). */
-int kx_mha_decode_wo_f32(const float* query, const float* key_cache, const float* value_cache,
-                         float* att_out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
-                         int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
-                         int32_t layer_index, const kx_gemv_w8_desc* wo, void* workspace,
-                         size_t workspace_bytes, void* stream);
 
 /* The same attention for a caller that has no zeroed workspace, only the reference's score tensor
  * ([head_num][seq_len] fp32, llama3.cpp:523-525, passed to every MHAKernel call,

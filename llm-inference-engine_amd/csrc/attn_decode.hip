@@ -16,11 +16,10 @@
 // arrival ticket in the workspace) merges the split results, so one launch does it all.
 #include <math.h>
 
-#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 
-#include "gemv_w8_dev.hpp"
+#include "kx_common.hpp"
 
 namespace kx {
 
@@ -145,33 +144,17 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
-// FUSE: the attention output projection (Wo, llama3.cpp:738-743) runs behind the attention in the
-// same launch.  After the key rows have been consumed the launch has a tail of several
-// microseconds in which nothing streams from HBM: partials travel to the workgroup that merges a
-// kv head, which draws its ticket, reads them back and writes the head outputs.  A GEMV's weights
-// do not depend on its input, so every workgroup requests its share of Wo's rows (the whole
-// matrix fits the grid's registers) while it waits; a counter of finished kv heads (one device-
-// scope release per merging workgroup, polled by one lane per workgroup, bounded) tells it when
-// the attention output is complete; then it stages that vector and finishes its rows.  Replaces a
-// kernel boundary plus a cold start of the memory pipeline.  Every workgroup of the grid must be
-// resident at once (the host checks the grid against the occupancy of the kernel).
-struct AttnWoArgs {
-  GemvW8Args g;     // x = the attention output vector, y0 / residual = the residual stream
-  unsigned* ready;  // finished kv heads, counted up by every launch (never reset)
-  unsigned* err;    // set when a wait gave up
-};
-constexpr unsigned kWoSpinLimit = 1u << 18;
-
 // PREFETCH: a wave with several tiles requests the next one before it consumes the current one
 // (costs a second set of tile registers; pointless when every wave has a single tile).
 // M4: the 4x4x1 form above (HS = 128, kv_mul <= 4).
-template <int HS, bool PREFETCH, typename KVT, bool M4 = false, bool FUSE = false, int WU = 4>
+template <int HS, bool PREFETCH, typename KVT, bool M4 = false>
 __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
     const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale,
-    unsigned long long* __restrict__ trace, const AttnWoArgs wo) {
-  // optional timeline (tools/bench_attn.py --trace): 8 wall-clock stamps (100 MHz) per workgroup
+    unsigned long long* __restrict__ trace) {
+  // optional timeline (tools/bench_attn.py with KX_ATTN_TRACE): wall-clock stamps (100 MHz), 8 per
+  // workgroup
   auto stamp = [&](int slot) {
     if (trace && threadIdx.x == 0)
       trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = wall_clock64();
@@ -184,7 +167,6 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   __shared__ __attribute__((aligned(16))) float sm_o[kAttnWaves][16][HS];
   __shared__ float sm_sf[kAttnWaves * kMaxSplits];  // final merge: split weights, one set per wave
   __shared__ int sm_last;
-  __shared__ float sm_red[16];
   __shared__ __attribute__((aligned(16))) float sm_p[M4 ? kAttnWaves * 64 : 4];  // M4: P of one tile per wave
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,40 +178,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   const int ntiles = (last >> 4) + 1;
   const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x, sizeof(KVT) == 4);
   const int nsplit = cut.nsplit;
-  // surplus workgroups of a grid cut for a longer context: nothing to attend to, but in the fused
-  // form they take their share of the projection
-  const bool active = split < nsplit;
-  if (!FUSE && !active) return;
-  // ---- fused projection: this workgroup's rows, their first (usually only) batch of weights ----
-  constexpr int WR = 8 / WU;  // rows per wave at a time: 8 loads of 16 bytes per lane in flight
-  GemvBatch<WR, WU, false> wB;
-  GemvRows<WR, false> wS;
-  unsigned ready0 = 0;
-  int w_r0 = 0, w_row_end = 0;
-  bool w_have = false;
-  auto wo_request = [&]() {
-    if constexpr (FUSE) {
-      const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-      const int row_begin = lin * wo.g.rows_per_block;
-      w_row_end = min(row_begin + wo.g.rows_per_block, wo.g.K);
-      w_r0 = row_begin + wave * WR;
-      w_have = w_r0 < w_row_end;
-      if (w_have) {
-        begin_rows<WR, GEMV_PLAIN>(wS);
-        // bias / residual of these rows: this workgroup alone rewrites them, at the very end
-        request_epilogue<WR, GEMV_PLAIN>(wo.g, w_r0, w_row_end, 0, wS);
-        load_batch<WR, WU, 1, 1, GEMV_PLAIN>(wo.g, w_r0, 0, w_row_end, lane * 16, wB.wv, wB.sc, wB.wv2,
-                                            wB.sc2);
-      }
-    }
-  };
-  if constexpr (FUSE) {
-    // the count before any kv head of THIS launch can have finished (all workgroups are resident
-    // and start together; the first increment is microseconds away)
-    if (threadIdx.x == 0) ready0 = __hip_atomic_load(wo.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wo_request();
-  }
-  if (active) {
+  if (split >= nsplit) return;
   const KVT* kbase = kc + (size_t)kvh * HS;
   const KVT* vbase = vc + (size_t)kvh * HS;
 
@@ -463,8 +412,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     }
     const int hq = kvh * kv_mul + head;
     if (nsplit == 1) {
-      if constexpr (FUSE) st_device(out + (size_t)hq * HS + d, O / L);
-      else out[(size_t)hq * HS + d] = O / L;
+      out[(size_t)hq * HS + d] = O / L;
     } else {
       // write-through (device-scope) stores: visible to the merging workgroup on any XCD without
       // a cache write-back
@@ -476,10 +424,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       st_device(dst + d, O);
     }
   }
-  if (!FUSE && nsplit == 1) return;
+  if (nsplit == 1) return;
 
-  bool finished_head = nsplit == 1;  // this workgroup wrote a kv head's final rows
-  if (nsplit > 1) {
   // ---- the workgroup that arrives last for this kv head combines the splits ----
   // Every storing wave drains its write-through stores before the workgroup takes a ticket; the
   // barrier orders them (workgroup scope) before thread 0's release fence, which publishes them
@@ -496,9 +442,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   }
   __syncthreads();
   stamp(4);  // ticket drawn
-  if (!FUSE && !sm_last) return;
-  if (sm_last) {
-  finished_head = true;
+  if (!sm_last) return;
   // Acquire at device scope, then ordinary 128-bit loads of the other workgroups' partials.
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // out[h][d] = sum_s O_s[d] e^{m_s-M} / sum_s l_s e^{m_s-M}.  One wave per head, no workgroup
@@ -565,70 +509,9 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       acc.z += __shfl_xor(acc.z, off);
       acc.w += __shfl_xor(acc.w, off);
     }
-    if (rg == 0) {
-      float* orow = out + (size_t)(kvh * kv_mul + head) * HS + c4;
-      if constexpr (FUSE) {
-        st_device(orow, acc.x); st_device(orow + 1, acc.y);
-        st_device(orow + 2, acc.z); st_device(orow + 3, acc.w);
-      } else {
-        *reinterpret_cast<f32x4*>(orow) = acc;
-      }
-    }
+    if (rg == 0) *reinterpret_cast<f32x4*>(out + (size_t)(kvh * kv_mul + head) * HS + c4) = acc;
   }
   stamp(5);  // this wave's heads merged
-  }  // sm_last
-  }  // nsplit > 1
-  if constexpr (FUSE) {
-    if (finished_head) {
-      // the kv head's output rows have reached memory; count the head as finished
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(wo.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  }  // active
-  if constexpr (FUSE) {
-    // ---- wait for every kv head, then the projection rows of this workgroup ----
-    if (threadIdx.x == 0) {
-      unsigned spins = 0;
-      while ((int)(__hip_atomic_load(wo.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ready0 -
-                   gridDim.x) < 0 &&
-             ++spins < kWoSpinLimit)
-        __builtin_amdgcn_s_sleep(1);
-      if (spins >= kWoSpinLimit)
-        __hip_atomic_fetch_or(wo.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // one invalidate of the CU's vector cache, ordered ahead of every wave's loads by the barrier
-    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    stamp(6);  // attention output complete
-    const GemvW8Args& a = wo.g;
-    f32x4* xs = reinterpret_cast<f32x4*>(&sm_o[0][0][0]);  // the wave results are consumed
-    GemvXRegsT<2> X;
-    request_x(a, threadIdx.x, X);
-    const float rs = commit_x(a, xs, sm_red, X);
-    if (w_have) {
-      consume<WR, WU, GEMV_PLAIN>(a, xs, lane, 0, wB, wS);
-      for (int c0 = WU; c0 < a.chunks; c0 += WU) {
-        load_batch<WR, WU, 1, 1, GEMV_PLAIN>(a, w_r0, c0, w_row_end, lane * 16, wB.wv, wB.sc, wB.wv2, wB.sc2);
-        consume<WR, WU, GEMV_PLAIN>(a, xs, lane, c0, wB, wS);
-      }
-      finish_rows<WR, GEMV_PLAIN>(a, w_r0, w_row_end, 0, rs, lane, wS);
-      for (int r0 = w_r0 + kAttnWaves * WR; r0 < w_row_end; r0 += kAttnWaves * WR) {
-        begin_rows<WR, GEMV_PLAIN>(wS);
-        request_epilogue<WR, GEMV_PLAIN>(a, r0, w_row_end, 0, wS);
-        for (int c0 = 0; c0 < a.chunks; c0 += WU) {
-          load_batch<WR, WU, 1, 1, GEMV_PLAIN>(a, r0, c0, w_row_end, lane * 16, wB.wv, wB.sc, wB.wv2, wB.sc2);
-          consume<WR, WU, GEMV_PLAIN>(a, xs, lane, c0, wB, wS);
-        }
-        finish_rows<WR, GEMV_PLAIN>(a, r0, w_row_end, 0, rs, lane, wS);
-      }
-    }
-    stamp(7);
-  }
 }
 
 // Any head size / any kv_mul: one workgroup per head, scores kept in a [head][seq_len] scratch
@@ -683,24 +566,12 @@ extern "C" size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size) {
          (size_t)head_num * kx::kMaxSplits * kx::attn_ws_stride(head_size) * sizeof(float);
 }
 
-// Residency of the fused kernel forms: workgroups of one instantiation that fit on the device at once.
-template <typename K>
-static int resident_capacity(K kernel, int* cap) {
-  int dev = 0, cus = 0, per_cu = 0;
-  KX_HIP_TRY(hipGetDevice(&dev));
-  KX_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  KX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel),
-                                                          kx::kAttnWaves * 64, 0));
-  *cap = cus * per_cu;
-  return KX_OK;
-}
-
 template <typename KVT>
 static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT* value_cache,
                              float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
                              int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                              int32_t layer_index, void* workspace, size_t workspace_bytes,
-                             void* stream, const kx_gemv_w8_desc* wo_desc = nullptr) {
+                             void* stream) {
   using namespace kx;
   if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
   if (pos < 0 || pos >= seq_len || head_num <= 0 || kv_mul <= 0 || head_num % kv_mul) return KX_EINVAL;
@@ -717,7 +588,7 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
                      (((uintptr_t)query | (uintptr_t)kc | (uintptr_t)vc) % 16 == 0) &&
                      kv_dim % 4 == 0;
   if (!tiled) {
-    if (pos_dev || !kFp32Cache || wo_desc) return KX_EUNSUPPORTED;
+    if (pos_dev || !kFp32Cache) return KX_EUNSUPPORTED;
     // the score rows sit behind the ticket words so the two paths can share one workspace
     if (!workspace || workspace_bytes < kTicketBytes + (size_t)head_num * seq_len * sizeof(float))
       return KX_EWORKSPACE;
@@ -752,44 +623,8 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // The grid keeps the two-per-CU split count even where the cut at `pos` falls back to one per CU:
   // a launch that reads its position from the device may see shorter contexts, for which the
   // finer cut is the better one (surplus workgroups leave at once).
-  // Fused projection: the grid keeps the full split count whatever the position (surplus
-  // workgroups only project), so the projection always has the whole chip.
-  AttnWoArgs wo{};
-  if (wo_desc) {
-    if (!kFp32Cache || kvh > kMaxTickets - 2) return KX_EUNSUPPORTED;
-    const int cap_splits = std::min(kMaxSplits, cap_grid);
-    const size_t need = kTicketBytes + (size_t)cap_splits * per_split;
-    if (!workspace || workspace_bytes < need) return KX_EWORKSPACE;
-    nsplit = cap_splits;
-    GemvW8Args& a = wo.g;
-    a.x = wo_desc->x; a.w = wo_desc->w; a.scales = wo_desc->scales;
-    a.y0 = a.y1 = a.y2 = wo_desc->y0;
-    a.bias = wo_desc->bias; a.residual = wo_desc->residual;
-    a.M = wo_desc->M; a.K = wo_desc->K;
-    a.k0 = a.k1 = a.K;
-    if (wo_desc->mode != KX_GEMV_PLAIN || wo_desc->norm_w || wo_desc->y1 || wo_desc->y2) return KX_EINVAL;
-    if (wo_desc->x != out || a.M != head_num * head_size || !a.w || !a.scales || !a.y0 || a.K <= 0)
-      return KX_EINVAL;
-    const int gs = wo_desc->group_size;
-    if (gs < 16 || (gs & (gs - 1)) || a.M % gs || a.M % 16 || ((uintptr_t)a.w % 16) ||
-        ((uintptr_t)out % 16))
-      return KX_EUNSUPPORTED;
-    a.chunks = (a.M + 1023) / 1024;
-    // x is staged where the wave results of the attention lived: [waves][16][head_size] floats
-    if ((size_t)a.chunks * 4096 > (size_t)kAttnWaves * 16 * head_size * sizeof(float)) return KX_EUNSUPPORTED;
-    int sh = 0;
-    while ((1 << sh) < gs) ++sh;
-    a.gs_shift = sh;
-    a.groups_per_row = a.M / gs;
-    const int R = a.chunks <= 2 ? 4 : 2;
-    const int nwg = kvh * nsplit;
-    a.rows_per_block = (((a.K + nwg - 1) / nwg + R - 1) / R) * R;
-    unsigned* words = reinterpret_cast<unsigned*>(workspace);
-    wo.ready = words + (kMaxTickets - 1) * (kTicketStride / sizeof(unsigned));
-    wo.err = words + (kMaxTickets - 2) * (kTicketStride / sizeof(unsigned));
-  }
   const AttnSplit cut = attn_split(ntiles, nsplit, kvh, kFp32Cache);
-  if (!pos_dev && !wo_desc) nsplit = cut.nsplit;
+  if (!pos_dev) nsplit = cut.nsplit;
   unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
   float* ws = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes) : nullptr;
   hipStream_t s = (hipStream_t)stream;
@@ -806,48 +641,14 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   do {                                                                                           \
     if (prefetch)                                                                                \
       hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace, wo);      \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace);                 \
     else                                                                                         \
       hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace, wo);      \
-  } while (0)
-  // fused projection (fp32 cache): the whole grid must be resident, or the in-launch wait for the
-  // attention output could starve the workgroups it waits for
-#define KX_ATTN_WO_LAUNCH_(HS_, M4_, PF_, WU_)                                                   \
-  do {                                                                                           \
-    auto kern = attn_decode_kernel<HS_, PF_, float, M4_, true, WU_>;                             \
-    int cap = 0;                                                                                 \
-    if (int rc = resident_capacity(kern, &cap)) return rc;                                       \
-    if ((int)(grid.x * grid.y) > cap) return KX_EUNSUPPORTED;                                    \
-    hipLaunchKernelGGL(kern, grid, block, 0, s, query, reinterpret_cast<const float*>(kc),       \
-                       reinterpret_cast<const float*>(vc), out, ws, tickets, pos, pos_dev, kv_mul, \
-                       kv_dim, scale, trace, wo);                                                \
-  } while (0)
-#define KX_ATTN_WO_LAUNCH(HS_, M4_)                                                              \
-  do {                                                                                           \
-    const bool narrow = wo.g.chunks <= 2;                                                        \
-    if (prefetch && narrow) KX_ATTN_WO_LAUNCH_(HS_, M4_, true, 2);                               \
-    else if (prefetch) KX_ATTN_WO_LAUNCH_(HS_, M4_, true, 4);                                    \
-    else if (narrow) KX_ATTN_WO_LAUNCH_(HS_, M4_, false, 2);                                     \
-    else KX_ATTN_WO_LAUNCH_(HS_, M4_, false, 4);                                                 \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace);                 \
   } while (0)
   // up to four query heads per kv head: the 4x4x1 form of the matrix instruction (a quarter of
   // the matrix-core cycles of the 16-column form, which leaves 12 head columns idle)
   const bool m4 = head_size == 128 && kv_mul <= 4;
-  if (wo_desc) {
-    if constexpr (kFp32Cache) {
-      switch (head_size) {
-        case 64: KX_ATTN_WO_LAUNCH(64, false); break;
-        case 128:
-          if (m4) KX_ATTN_WO_LAUNCH(128, true);
-          else KX_ATTN_WO_LAUNCH(128, false);
-          break;
-        default: return KX_EUNSUPPORTED;
-      }
-    }
-    KX_LAUNCH_CHECK();
-    return KX_OK;
-  }
   switch (head_size) {
     case 32: KX_ATTN_LAUNCH(32, false); break;
     case 64: KX_ATTN_LAUNCH(64, false); break;
@@ -858,8 +659,6 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
     default: return KX_EUNSUPPORTED;
   }
 #undef KX_ATTN_LAUNCH
-#undef KX_ATTN_WO_LAUNCH
-#undef KX_ATTN_WO_LAUNCH_
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -872,18 +671,6 @@ extern "C" int kx_mha_decode_f32(const float* query, const float* key_cache,
   return mha_decode_launch<float>(query, key_cache, value_cache, out, pos, nullptr, head_num, kv_mul,
                            head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
                            stream);
-}
-
-extern "C" int kx_mha_decode_wo_f32(const float* query, const float* key_cache,
-                                    const float* value_cache, float* att_out, int32_t pos,
-                                    const int32_t* pos_dev, int32_t head_num, int32_t kv_mul,
-                                    int32_t head_size, int32_t kv_dim, int32_t seq_len,
-                                    int32_t layer_index, const kx_gemv_w8_desc* wo, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
-  if (!wo) return KX_EINVAL;
-  return mha_decode_launch<float>(query, key_cache, value_cache, att_out, pos, pos_dev, head_num,
-                                  kv_mul, head_size, kv_dim, seq_len, layer_index, workspace,
-                                  workspace_bytes, stream, wo);
 }
 
 extern "C" int kx_mha_decode_scores_f32(const float* query, const float* key_cache,

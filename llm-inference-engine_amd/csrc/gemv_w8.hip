@@ -24,12 +24,313 @@
 // Rounding order differs from the reference only in where the scale is applied: the 16
 // products x*w of a lane are summed first and the group scale multiplies that partial sum.
 #include <algorithm>
-#include <cstdlib>
 #include "gemv_w8.hpp"
 
-#include "gemv_w8_dev.hpp"
-
 namespace kx {
+
+__device__ __forceinline__ float dot16(const i32x4 wv, const f32x4 x0, const f32x4 x1,
+                                       const f32x4 x2, const f32x4 x3) {
+  float a = 0.f;
+#define KX_B(word, sh) ((float)(int8_t)((word) >> (sh)))
+  a = fmaf(x0.x, KX_B(wv.x, 0), a);
+  a = fmaf(x0.y, KX_B(wv.x, 8), a);
+  a = fmaf(x0.z, KX_B(wv.x, 16), a);
+  a = fmaf(x0.w, KX_B(wv.x, 24), a);
+  a = fmaf(x1.x, KX_B(wv.y, 0), a);
+  a = fmaf(x1.y, KX_B(wv.y, 8), a);
+  a = fmaf(x1.z, KX_B(wv.y, 16), a);
+  a = fmaf(x1.w, KX_B(wv.y, 24), a);
+  a = fmaf(x2.x, KX_B(wv.z, 0), a);
+  a = fmaf(x2.y, KX_B(wv.z, 8), a);
+  a = fmaf(x2.z, KX_B(wv.z, 16), a);
+  a = fmaf(x2.w, KX_B(wv.z, 24), a);
+  a = fmaf(x3.x, KX_B(wv.w, 0), a);
+  a = fmaf(x3.y, KX_B(wv.w, 8), a);
+  a = fmaf(x3.z, KX_B(wv.w, 16), a);
+  a = fmaf(x3.w, KX_B(wv.w, 24), a);
+#undef KX_B
+  return a;
+}
+
+// Virtual row v -> matrix row.  With half-split RoPE the two rows of a rotation pair are hs/2
+// apart; the virtual order puts them next to each other so one wave finishes both.
+template <int MODE>
+__device__ __forceinline__ int map_row(const GemvW8Args& a, int v) {
+  if constexpr (MODE == GEMV_QKV_ROPE) {
+    if (a.rope_variant == KX_ROPE_HALF_SPLIT && v < a.k1) {
+      const int hs = a.head_size;
+      const int head = v / hs, i = v - head * hs;
+      return head * hs + (i >> 1) + (i & 1) * (hs >> 1);
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, float*& dst, int& r) {
+  if (row < a.k0) {
+    dst = a.y0;
+    r = row;
+  } else if (row < a.k1) {
+    dst = a.y1 + (size_t)pos * a.kv_pos_stride;
+    r = row - a.k0;
+  } else {
+    dst = a.y2 + (size_t)pos * a.kv_pos_stride;
+    r = row - a.k1;
+  }
+}
+
+// Row of the stacked q|k|v product -> its destination; k and v rows go to the position's cache row,
+// rounded to fp16 when the cache holds fp16.
+__device__ __forceinline__ void store_routed(const GemvW8Args& a, int row, int pos, float v) {
+  if (a.kv_f16 && row >= a.k0) {
+    const bool is_k = row < a.k1;
+    _Float16* dst = reinterpret_cast<_Float16*>(is_k ? a.y1 : a.y2) + (size_t)pos * a.kv_pos_stride;
+    dst[row - (is_k ? a.k0 : a.k1)] = (_Float16)v;
+    return;
+  }
+  float* dst;
+  int rr;
+  route(a, row, pos, dst, rr);
+  dst[rr] = v;
+}
+
+// Issues the 128-bit weight loads (and the one scale per load) of U chunks of R rows.
+template <int R, int U, int R2, int U2, int MODE>
+__device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, int row_end,
+                                           int col_lane, i32x4 (&wv)[R][U], float (&sc)[R][U],
+                                           i32x4 (&wv2)[R2][U2], float (&sc2)[R2][U2]) {
+  constexpr bool GU = MODE == GEMV_GATE_UP;
+  int rows[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) rows[r] = map_row<MODE>(a, min(r0 + r, row_end - 1));
+  // issue order = consumption order (chunk-major), so the first products can start while the
+  // later loads are still in flight
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    // Columns past M re-read the row's last 16 weights: x is staged as zero there, so the products
+    // vanish.  Unconditional loads matter: under a per-lane column test the compiler branches
+    // around every load and waits for the whole batch before the first product.
+    const int col = min((c0 + u) * 1024 + col_lane, a.M - 16);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rows[r];
+      const size_t off = (size_t)row * (size_t)a.M + (size_t)col;
+      wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
+      sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
+                                            (col >> a.gs_shift));
+      if constexpr (GU) {
+        const size_t off2 = off + (size_t)a.swiglu_half * (size_t)a.M;
+        wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
+        sc2[r][u] = __builtin_nontemporal_load(
+            a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
+      }
+    }
+  }
+}
+
+// Staging of x in LDS: slot (c*4+p)*64+l <- x[c*1024 + l*16 + p*4 .. +4), zero past M.  With a
+// norm weight g the staged vector is g*x and commit_x returns rsqrt(mean(x^2)+eps), which the
+// caller applies to the finished row sums: norm_w * (rs * x) of cpu/rmsnorm_kernel.cpp:30-32 with
+// the scalar factored out of the dot product.
+//
+// Two steps, because loads return in order: request_x asks for a thread's first four vectors
+// BEFORE the first weight batch is requested, commit_x (after it) waits for them only -- the
+// weights stay in flight across the LDS writes, the barrier and the norm reduction.  Requested
+// behind the weights, x could not be touched before every weight of the batch had arrived.
+constexpr int kXPer = 4;  // loads per thread and pass, all requested before the first is used
+struct GemvXRegs {
+  f32x4 v[kXPer];
+  f32x4 g[kXPer];
+};
+
+// Unconditional loads with a clamped index: a load under a test would be waited for on its own.
+__device__ __forceinline__ void request_x(const GemvW8Args& a, int i0, GemvXRegs& X) {
+  const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
+  const f32x4* ng = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
+  const int m4 = a.M >> 2, bd = blockDim.x;
+#pragma unroll
+  for (int j = 0; j < kXPer; ++j) {
+    const int idx = min(i0 + j * bd, m4 - 1);
+    X.v[j] = xg[idx];
+    if (a.norm_w) X.g[j] = ng[idx];
+  }
+}
+
+// One pass of staging: the kXPer vectors of X (requested for pass start i0) go to LDS; returns
+// their sum of squares.
+__device__ __forceinline__ float stage_pass(const GemvW8Args& a, f32x4* xs, int i0, bool norm,
+                                            const GemvXRegs& X) {
+  const int n4 = a.chunks * 256, m4 = a.M >> 2, bd = blockDim.x;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < kXPer; ++j) {
+    const int i = i0 + j * bd;
+    if (i < n4) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (i < m4) {
+        o = X.v[j];
+        ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+        if (norm) o = f32x4{X.g[j].x * o.x, X.g[j].y * o.y, X.g[j].z * o.z, X.g[j].w * o.w};
+      }
+      const int c = i >> 8, l = (i >> 2) & 63, p = i & 3;
+      xs[((c * 4 + p) << 6) + l] = o;
+    }
+  }
+  return ss;
+}
+
+// Ends with one workgroup barrier.  The first pass (requested ahead of the weights) is straight-
+// line code of its own: sharing a loop body with the later passes, whose loads are the youngest
+// in flight, it would inherit their wait and sit until the weights had arrived too.
+__device__ __forceinline__ float commit_x(const GemvW8Args& a, f32x4* xs, float* red, GemvXRegs& X) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6, bd = blockDim.x;
+  const int n4 = a.chunks * 256;
+  const bool norm = a.norm_w != nullptr;
+  float ss = stage_pass(a, xs, tid, norm, X);
+  for (int i0 = tid + kXPer * bd; i0 < n4; i0 += kXPer * bd) {
+    request_x(a, i0, X);
+    ss += stage_pass(a, xs, i0, norm, X);
+  }
+  float rs = 1.0f;
+  if (norm) {
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+  }
+  __syncthreads();
+  if (norm) {
+    float tot = 0.f;
+    for (int w = 0; w < nwaves; ++w) tot += red[w];
+    rs = 1.0f / sqrtf(tot / (float)a.M + a.norm_eps);
+  }
+  return rs;
+}
+
+// One batch of weights in registers: R rows x U chunks (and the paired "up" rows for gate/up).
+template <int R, int U, bool GU>
+struct GemvBatch {
+  i32x4 wv[R][U];
+  float sc[R][U];
+  i32x4 wv2[GU ? R : 1][GU ? U : 1];
+  float sc2[GU ? R : 1][GU ? U : 1];
+};
+
+// Row totals and the epilogue operands of the R rows a wave is working on.
+template <int R, bool GU>
+struct GemvRows {
+  float total[R];
+  float total2[GU ? R : 1];
+  float bias[R];                       // 0 without a bias vector
+  float residual[R];                   // 0 without a residual vector
+  float rope_s[R / 2 > 0 ? R / 2 : 1];  // sin / cos of each rotation pair
+  float rope_c[R / 2 > 0 ? R / 2 : 1];
+};
+
+template <int R, int MODE>
+__device__ __forceinline__ void begin_rows(GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    S.total[r] = 0.f;
+    if constexpr (MODE == GEMV_GATE_UP) S.total2[r] = 0.f;
+  }
+}
+
+// Requests the epilogue operands of a row set ahead of its weights, so no dependent load is left
+// for the tail.  The values are only assigned here, never used: a use under the pointer test would
+// put a full wait inside the branch, one memory round trip per operand before the first weight is
+// requested.  (Requesting them behind the last weight batch instead measured the same on the
+// token loop and 3-6 % slower on the large plain shapes.)
+template <int R, int MODE>
+__device__ __forceinline__ void request_epilogue(const GemvW8Args& a, int r0, int row_end, int pos,
+                                                 GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
+    float b = 0.f, res = 0.f;
+    if (a.bias) b = a.bias[row];
+    if constexpr (MODE != GEMV_QKV_ROPE) {
+      if (a.residual) res = a.residual[row];
+    } else if ((r & 1) == 0) {
+      // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
+      const int in_head = row % a.head_size;
+      const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
+      S.rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
+      S.rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];
+    }
+    S.bias[r] = b;
+    S.residual[r] = res;
+  }
+}
+
+// Products of one batch against the staged x.
+template <int R, int U, int MODE>
+__device__ __forceinline__ void consume(const GemvW8Args& a, const f32x4* xs, int lane, int c0,
+                                        const GemvBatch<R, U, MODE == GEMV_GATE_UP>& B,
+                                        GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (c0 + u < a.chunks) {
+      const int base = ((c0 + u) * 4) << 6;
+      const f32x4 x0 = xs[base + lane];
+      const f32x4 x1 = xs[base + 64 + lane];
+      const f32x4 x2 = xs[base + 128 + lane];
+      const f32x4 x3 = xs[base + 192 + lane];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        S.total[r] = fmaf(dot16(B.wv[r][u], x0, x1, x2, x3), B.sc[r][u], S.total[r]);
+        if constexpr (MODE == GEMV_GATE_UP)
+          S.total2[r] = fmaf(dot16(B.wv2[r][u], x0, x1, x2, x3), B.sc2[r][u], S.total2[r]);
+      }
+    }
+  }
+}
+
+// Wave reduction and epilogue of R finished rows.
+template <int R, int MODE>
+__device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row_end, int pos,
+                                            float rs, int lane,
+                                            GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    S.total[r] = wave_sum(S.total[r]) * rs;
+    if constexpr (MODE == GEMV_GATE_UP) {
+      const float up = wave_sum(S.total2[r]) * rs;
+      // swiglu_kernel_cu (cuda/swiglu_kernel.cu:4-22): gate * sigmoid(gate) * up
+      S.total[r] = S.total[r] * (1.0f / (1.0f + expf(-S.total[r]))) * up;
+    }
+  }
+  if (lane != 0) return;
+  if constexpr (MODE == GEMV_QKV_ROPE) {
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      const int v = r0 + r;
+      if (v < row_end) {  // row counts are even, so v+1 is valid too
+        const int row0 = map_row<MODE>(a, v), row1 = map_row<MODE>(a, v + 1);
+        float o0 = S.total[r] + S.bias[r], o1 = S.total[r + 1] + S.bias[r + 1];
+        if (v < a.k1) {
+          const float fci = S.rope_s[r / 2], fcr = S.rope_c[r / 2];
+          const float t0 = o0 * fcr - o1 * fci;
+          const float t1 = o0 * fci + o1 * fcr;
+          o0 = t0;
+          o1 = t1;
+        }
+        store_routed(a, row0, pos, o0);
+        store_routed(a, row1, pos, o1);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r0 + r;
+      if (row < row_end) {
+        float* dst;
+        int rr;
+        route(a, row, 0, dst, rr);
+        dst[rr] = S.total[r] + (S.bias[r] + S.residual[r]);
+      }
+    }
+  }
+}
 
 // R rows per wave at a time (R even for GEMV_QKV_ROPE), U chunk loads per row in flight.
 // For shapes where a wave gets a single batch (or a few).
@@ -138,169 +439,6 @@ __global__ void gemv_w8_generic_kernel(const GemvW8Args a, int32_t group_size) {
   }
 }
 
-// ---- several dependent GEMVs in one launch -------------------------------------------------
-// A decode layer is a chain of matrix-vector products, each consuming the previous one's whole
-// output: as separate launches every link pays the kernel boundary and the ramp of a cold memory
-// pipeline.  But a GEMV's weights do not depend on its input vector: here one grid (one 16-wave
-// workgroup per CU, all resident) walks the chain, and before it waits at the grid barrier that
-// guards stage n+1's input each wave has already requested its first batch of stage n+1's weights,
-// so HBM keeps streaming across the seam.  Stage outputs leave as write-through device-scope
-// stores; the barrier is a release/acquire pair at device scope.
-//
-// Barrier state (zeroed once by the owner, then reused by every launch of the SAME grid size):
-// the workgroups form kChainGroups groups by blockIdx % 8 (round-robin placement puts a group on
-// one XCD: a speed matter only).  Arrivals count up on the group's word; the group's last arriver
-// counts up the top word, waits for all groups, and publishes the group's generation, on which
-// the rest of the group polls.  Counters only grow (compared modulo 2^32), so nothing is reset.
-// Every spin is bounded: on giving up a workgroup raises the error word and runs on, so the grid
-// always drains.
-constexpr int kChainGroups = 8;
-constexpr int kChainWordStride = 64;  // 256 bytes between the words
-constexpr int kChainErrWord = (2 * kChainGroups + 1) * kChainWordStride;
-constexpr size_t kChainStateBytes = (2 * kChainGroups + 2) * kChainWordStride * sizeof(unsigned);
-constexpr int kChainMaxStages = 4;
-constexpr int kChainThreads = 1024;
-constexpr unsigned kChainSpinLimit = 1u << 18;  // polls of ~1 us each: a quarter of a second
-
-struct GemvChainArgs {
-  GemvW8Args st[kChainMaxStages];
-  int32_t mode[kChainMaxStages];
-  int32_t n;
-  unsigned* bar;
-  // optional timeline (tools/bench_chain.py): 16 wall-clock stamps (100 MHz) per workgroup
-  unsigned long long* trace;
-};
-constexpr int kChainTraceSlots = 16;
-
-__device__ __forceinline__ void chain_stamp(unsigned long long* trace, int slot) {
-  if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * kChainTraceSlots + slot] = wall_clock64();
-}
-
-__device__ __forceinline__ unsigned chain_ld(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-struct ChainBarrier {
-  unsigned* cnt;   // this group's arrival counter
-  unsigned* genw;  // this group's published generation
-  unsigned* top;
-  unsigned* err;
-  unsigned gen, group_size, ngroups;
-
-  __device__ void init(unsigned* base) {
-    const unsigned grid = gridDim.x, g = blockIdx.x % kChainGroups;
-    ngroups = grid < (unsigned)kChainGroups ? grid : (unsigned)kChainGroups;
-    group_size = (grid - g + kChainGroups - 1) / kChainGroups;
-    cnt = base + g * kChainWordStride;
-    genw = base + (kChainGroups + g) * kChainWordStride;
-    top = base + 2 * kChainGroups * kChainWordStride;
-    err = base + kChainErrWord;
-    // stable for the whole group until every one of its workgroups has arrived at a barrier
-    gen = chain_ld(genw);
-  }
-
-  // All workgroups of the grid meet here.  Stores issued before it (write-through) are visible
-  // to every load issued after it.
-  __device__ void sync() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
-    __syncthreads();
-    ++gen;
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      if (old + 1u == group_size * gen) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(chain_ld(top) - ngroups * gen) < 0 && ++spins < kChainSpinLimit)
-          __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        __hip_atomic_store(genw, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        while ((int)(chain_ld(genw) - gen) < 0 && ++spins < kChainSpinLimit)
-          __builtin_amdgcn_s_sleep(1);
-      }
-      if (spins >= kChainSpinLimit)
-        __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // One cache invalidate per workgroup: the vector cache it acts on belongs to the CU, and the
-    // workgroup barrier below orders it ahead of every other wave's loads.  (Issued by all 16
-    // waves of all workgroups it cost ~40 us per barrier.)
-    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-  }
-};
-
-// One stage on this workgroup's share of the rows.  `wait` = the stage reads what an earlier
-// stage of this launch wrote: the first weight batch is requested, THEN the grid meets, then x is
-// staged (epilogue operands too: a residual may be an earlier stage's output).
-template <int R, int U, int MODE>
-__device__ __forceinline__ void chain_stage(const GemvW8Args& a, f32x4* xs, float* red,
-                                            ChainBarrier& bar, bool wait,
-                                            unsigned long long* trace, int slot0) {
-  constexpr bool GU = MODE == GEMV_GATE_UP;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int out_rows = GU ? a.swiglu_half : a.K;
-  const int row_begin = blockIdx.x * a.rows_per_block;
-  const int row_end = min(row_begin + a.rows_per_block, out_rows);
-  const int col_lane = lane * 16;
-  int r0 = row_begin + wave * R;
-  const bool have = r0 < row_end;
-
-  GemvBatch<R, U, GU> B;
-  GemvRows<R, GU> S;
-  if (have) {
-    begin_rows<R, MODE>(S);
-    load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, 0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
-  }
-  chain_stamp(trace, slot0);
-  if (wait) bar.sync();
-  chain_stamp(trace, slot0 + 1);
-  // 16 waves stage x: one or two vectors a thread cover up to 8 chunks in a single pass
-  GemvXRegsT<2> X;
-  request_x(a, threadIdx.x, X);
-  const float rs = commit_x(a, xs, red, X);
-  chain_stamp(trace, slot0 + 2);
-  if (!have) return;
-  int pos = 0;
-  if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
-  request_epilogue<R, MODE>(a, r0, row_end, pos, S);
-  consume<R, U, MODE>(a, xs, lane, 0, B, S);
-  for (int c0 = U; c0 < a.chunks; c0 += U) {
-    load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
-    consume<R, U, MODE>(a, xs, lane, c0, B, S);
-  }
-  finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
-  for (r0 += nwaves * R; r0 < row_end; r0 += nwaves * R) {
-    begin_rows<R, MODE>(S);
-    request_epilogue<R, MODE>(a, r0, row_end, pos, S);
-    for (int c0 = 0; c0 < a.chunks; c0 += U) {
-      load_batch<R, U, GU ? R : 1, GU ? U : 1, MODE>(a, r0, c0, row_end, col_lane, B.wv, B.sc, B.wv2, B.sc2);
-      consume<R, U, MODE>(a, xs, lane, c0, B, S);
-    }
-    finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
-  }
-}
-
-__global__ __launch_bounds__(kChainThreads) void gemv_chain_kernel(const GemvChainArgs c) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* xs = reinterpret_cast<f32x4*>(smem);
-  __shared__ float red[16];
-  ChainBarrier bar;
-  bar.init(c.bar);
-#pragma unroll
-  for (int i = 0; i < kChainMaxStages; ++i) {
-    if (i >= c.n) break;
-    const GemvW8Args& a = c.st[i];
-    switch (c.mode[i]) {
-      case GEMV_GATE_UP: chain_stage<1, 2, GEMV_GATE_UP>(a, xs, red, bar, i > 0, c.trace, 3 * i); break;
-      case GEMV_QKV_ROPE: chain_stage<2, 2, GEMV_QKV_ROPE>(a, xs, red, bar, i > 0, c.trace, 3 * i); break;
-      default: chain_stage<1, 4, GEMV_PLAIN>(a, xs, red, bar, i > 0, c.trace, 3 * i); break;
-    }
-  }
-  chain_stamp(c.trace, 3 * kChainMaxStages);
-}
-
 template <int R, int U, int MODE>
 static int launch(const GemvW8Args& a, int threads, hipStream_t s) {
   const int out_rows = MODE == GEMV_GATE_UP ? a.swiglu_half : a.K;
@@ -325,24 +463,16 @@ static int ilog2(int v) {
   return s;
 }
 
-// Argument checks shared by the single-launch and the chained form; *fast = the 16-byte-chunk
-// kernels apply.
-static int gemv_w8_check(const GemvW8Args& a, int32_t group_size, bool* fast) {
+int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) {
   if (!a.x || !a.w || !a.scales || !a.y0) return KX_EINVAL;
   if (a.M <= 0 || a.K <= 0 || group_size <= 0) return KX_EINVAL;
   if (a.M % 4 != 0) return KX_EINVAL;  // matmul_kernel.cu:123
   if (((size_t)a.M * (size_t)a.K) % (size_t)group_size != 0) return KX_EINVAL;
   const bool pow2 = (group_size & (group_size - 1)) == 0;
-  *fast = pow2 && group_size % 16 == 0 && a.M % group_size == 0 && a.M % 16 == 0 &&
-          ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&
-          (!a.norm_w || (uintptr_t)a.norm_w % 16 == 0) &&
-          (size_t)((a.M + 1023) / 1024) * 4096 <= 160 * 1024 - 64;
-  return KX_OK;
-}
-
-int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) {
-  bool fast = false;
-  if (int rc = gemv_w8_check(a, group_size, &fast)) return rc;
+  const bool fast = pow2 && group_size % 16 == 0 && a.M % group_size == 0 && a.M % 16 == 0 &&
+                    ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&
+                    (!a.norm_w || (uintptr_t)a.norm_w % 16 == 0) &&
+                    (size_t)((a.M + 1023) / 1024) * 4096 <= 160 * 1024 - 64;
   if (!fast) {
     if (mode != GEMV_PLAIN || a.norm_w) return KX_EUNSUPPORTED;
     const int wpb = 4;
@@ -436,74 +566,9 @@ extern "C" int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const fl
   return kx::gemv_w8_dispatch(a, group_size, kx::GEMV_GATE_UP, (hipStream_t)stream);
 }
 
-static int args_from_desc(const kx_gemv_w8_desc* d, kx::GemvW8Args& a);
-
 extern "C" int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* d, void* stream) {
   if (!d) return KX_EINVAL;
   kx::GemvW8Args a{};
-  if (int rc = args_from_desc(d, a)) return rc;
-  return kx::gemv_w8_dispatch(a, d->group_size, d->mode, (hipStream_t)stream);
-}
-
-extern "C" size_t kx_gemv_chain_state_bytes(void) { return kx::kChainStateBytes; }
-
-extern "C" int kx_gemv_w8_chain_f32(const kx_gemv_w8_desc* descs, int32_t n, void* state,
-                                    size_t state_bytes, void* stream) {
-  using namespace kx;
-  if (!descs || n < 1 || n > kChainMaxStages) return KX_EINVAL;
-  if (!state || state_bytes < kChainStateBytes || (uintptr_t)state % 256) return KX_EWORKSPACE;
-  // one workgroup per CU: every workgroup is resident, so the in-launch barriers complete
-  static int cus_of[64];
-  int dev = 0;
-  KX_HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return KX_EUNSUPPORTED;
-  if (!cus_of[dev]) {
-    int cus = 0;
-    KX_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus <= 0) return KX_EUNSUPPORTED;
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_chain_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    int per_cu = 0;
-    KX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, reinterpret_cast<const void*>(&gemv_chain_kernel), kChainThreads, 160 * 1024 - 64));
-    if (per_cu < 1) return KX_EUNSUPPORTED;
-    cus_of[dev] = cus;
-  }
-  const int grid = cus_of[dev];
-  GemvChainArgs c{};
-  c.n = n;
-  c.bar = static_cast<unsigned*>(state);
-  // a state buffer with room for it, and KX_CHAIN_TRACE set: per-workgroup timeline behind the words
-  if (state_bytes >= kChainStateBytes + (size_t)grid * kChainTraceSlots * 8 && getenv("KX_CHAIN_TRACE"))
-    c.trace = reinterpret_cast<unsigned long long*>(static_cast<char*>(state) + kChainStateBytes);
-  size_t lds = 0;
-  for (int i = 0; i < n; ++i) {
-    const kx_gemv_w8_desc* d = descs + i;
-    GemvW8Args& a = c.st[i];
-    if (int rc = args_from_desc(d, a)) return rc;
-    bool fast = false;
-    if (int rc = gemv_w8_check(a, d->group_size, &fast)) return rc;
-    if (!fast) return KX_EUNSUPPORTED;
-    a.chunks = (a.M + 1023) / 1024;
-    a.gs_shift = ilog2(d->group_size);
-    a.groups_per_row = a.M / d->group_size;
-    a.coherent_out = i + 1 < n;
-    c.mode[i] = d->mode;
-    if (d->mode == GEMV_QKV_ROPE && (a.K % 2 || a.k0 % 2 || a.k1 % 2 || a.head_size % 2))
-      return KX_EINVAL;
-    const int out_rows = d->mode == GEMV_GATE_UP ? a.swiglu_half : a.K;
-    const int R = d->mode == GEMV_QKV_ROPE ? 2 : 1;
-    int rpb = (out_rows + grid - 1) / grid;
-    rpb = ((rpb + R - 1) / R) * R;
-    a.rows_per_block = rpb;
-    lds = std::max(lds, (size_t)a.chunks * 4096);
-  }
-  hipLaunchKernelGGL(gemv_chain_kernel, dim3(grid), dim3(kChainThreads), lds, (hipStream_t)stream, c);
-  KX_LAUNCH_CHECK();
-  return KX_OK;
-}
-
-static int args_from_desc(const kx_gemv_w8_desc* d, kx::GemvW8Args& a) {
   a.x = d->x; a.w = d->w; a.scales = d->scales;
   a.norm_w = d->norm_w; a.norm_eps = d->norm_eps;
   a.M = d->M; a.K = d->K;
@@ -536,5 +601,5 @@ static int args_from_desc(const kx_gemv_w8_desc* d, kx::GemvW8Args& a) {
   }
   if (k0 < 0 || k1 < k0 || k1 > d->K) return KX_EINVAL;
   a.k0 = k0; a.k1 = k1;
-  return KX_OK;
+  return kx::gemv_w8_dispatch(a, d->group_size, d->mode, (hipStream_t)stream);
 }

@@ -33,9 +33,6 @@ struct GemvW8Args {
   int32_t head_size;
   int32_t kv_pos_stride;  // y1/y2 are advanced by pos * kv_pos_stride elements (KV-cache row)
   int32_t kv_f16;         // GEMV_QKV_ROPE: y1/y2 point at fp16 cache rows
-  // non-zero: results leave as write-through device-scope stores (a later stage of the same
-  // launch, on another CU, reads them after a grid barrier)
-  int32_t coherent_out;
 };
 
 int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s);

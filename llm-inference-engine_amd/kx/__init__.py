@@ -76,8 +76,6 @@ SIGNATURES = {
     "kx_flash_attention_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _sz, _vp]),
-    "kx_mha_decode_wo_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32,
-                                       _i32, _vp, _vp, _sz, _vp]),
     "kx_mha_decode_scores_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                            _i32, _vp, _sz, _vp]),
     "kx_mha_decode_static_limit_bytes": (_sz, []),
@@ -106,8 +104,6 @@ SIGNATURES = {
     "kx_step_workspace_bytes": (_sz, []),
     "kx_decode_step_end": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "kx_gemv_w8_fused_f32": (C.c_int, [_vp, _vp]),
-    "kx_gemv_chain_state_bytes": (_sz, []),
-    "kx_gemv_w8_chain_f32": (C.c_int, [_vp, _i32, _vp, _sz, _vp]),
     "kx_fill_hash_i8": (C.c_int, [_vp, _i32, _i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _vp]),
     "kx_fill_hash_f32": (C.c_int, [_vp, _i32, _i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _f,
                                    _f, _vp]),

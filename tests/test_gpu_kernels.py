@@ -135,75 +135,6 @@ def test_gemv_w8_full_size_linearity():
         assert abs(y1[r] - want) <= 1e-5 * w8_abs_sum(x1, w[r:r + 1], s[r * M // GS:(r + 1) * M // GS])
 
 
-# ------------------------------- chained GEMVs in one launch ------------------------------------
-def _chain_case(dim, hid, H, KVH, hs, n_stages, seed):
-    """Wo(+residual) -> RMSNorm+W1|W3+SwiGLU -> W2(+residual) -> RMSNorm+Wq|Wk|Wv+RoPE+cache row,
-    every stage reading the previous one's output, with the oracle's answer for each buffer."""
-    rng = np.random.default_rng(seed)
-    kvd, S, pos = KVH * hs, 48, 33
-    qkv_rows = H * hs + 2 * kvd
-    mats = {n: rand_w8(rng, K, M)[1:] for n, (K, M) in
-            dict(wo=(dim, H * hs), w13=(2 * hid, dim), w2=(dim, hid), qkv=(qkv_rows, dim)).items()}
-    for n in mats:
-        mats[n] = (mats[n][0], mats[n][1] * 8)
-    att = rng.standard_normal(H * hs).astype(np.float32)
-    x0 = rng.standard_normal(dim).astype(np.float32)
-    g1 = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
-    g2 = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
-    sin, cos = kxo.sin_cos_cache(hs, S, 5e5)
-    # oracle
-    x1 = x0 + kxo.gemv_w8(att, *mats["wo"], GS, threads=8)
-    full = kxo.gemv_w8(kxo.rmsnorm(x1, g1, 1e-5), *mats["w13"], GS, threads=8)
-    h = kxo.swiglu(full[:hid], full[hid:])
-    x2 = x1 + kxo.gemv_w8(h, *mats["w2"], GS, threads=8)
-    qkv = kxo.gemv_w8(kxo.rmsnorm(x2, g2, 1e-5), *mats["qkv"], GS, threads=8)
-    q, k = kxo.rope(1, H * hs, kvd, hs, qkv[:H * hs], qkv[H * hs:H * hs + kvd], pos, sin, cos)
-    want = dict(x1=x1, h=h, x2=x2, q=q, k=k, v=qkv[H * hs + kvd:])
-    dev = {n: (kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)) for n, (w, s) in mats.items()}
-    b = dict(att=kx.Buf.from_numpy(att), x=kx.Buf.from_numpy(x0), h=kx.Buf.zeros(hid),
-             q=kx.Buf.zeros(H * hs), kc=kx.Buf.zeros((S, kvd)), vc=kx.Buf.zeros((S, kvd)),
-             g1=kx.Buf.from_numpy(g1), g2=kx.Buf.from_numpy(g2), sin=kx.Buf.from_numpy(sin),
-             cos=kx.Buf.from_numpy(cos), pos=kx.Buf.from_numpy(np.array([pos], np.int32)))
-    D = kx.GemvDesc
-    descs = (D * 4)(
-        D(mode=0, group_size=GS, M=H * hs, K=dim, x=b["att"].ptr, w=dev["wo"][0].ptr,
-          scales=dev["wo"][1].ptr, y0=b["x"].ptr, residual=b["x"].ptr),
-        D(mode=1, group_size=GS, M=dim, K=2 * hid, x=b["x"].ptr, w=dev["w13"][0].ptr,
-          scales=dev["w13"][1].ptr, norm_w=b["g1"].ptr, norm_eps=1e-5, y0=b["h"].ptr),
-        D(mode=0, group_size=GS, M=hid, K=dim, x=b["h"].ptr, w=dev["w2"][0].ptr,
-          scales=dev["w2"][1].ptr, y0=b["x"].ptr, residual=b["x"].ptr),
-        D(mode=2, group_size=GS, M=dim, K=qkv_rows, x=b["x"].ptr, w=dev["qkv"][0].ptr,
-          scales=dev["qkv"][1].ptr, norm_w=b["g2"].ptr, norm_eps=1e-5, y0=b["q"].ptr, y1=b["kc"].ptr,
-          y2=b["vc"].ptr, k0=H * hs, k1=H * hs + kvd, sin_cache=b["sin"].ptr, cos_cache=b["cos"].ptr,
-          pos_dev=b["pos"].ptr, rope_variant=1, head_size=hs, kv_pos_stride=kvd))
-    return descs, b, dev, want, pos
-
-
-@pytest.mark.parametrize("dim,hid,H,KVH,hs", [(256, 512, 4, 2, 64), (1024, 2816, 8, 2, 128),
-                                              (4096, 14336, 32, 8, 128), (2048, 8192, 32, 8, 64),
-                                              (3584, 4736, 7, 1, 128)])
-def test_gemv_chain_one_launch_vs_oracle_and_separate_launches(dim, hid, H, KVH, hs):
-    L = kx.lib()
-    state = kx.Buf.zeros(L.kx_gemv_chain_state_bytes(), np.uint8)
-    for n_stages in (4, 3, 1, 2, 4):   # one state buffer across launches of different lengths
-        descs, b, dev, want, pos = _chain_case(dim, hid, H, KVH, hs, n_stages, seed=dim + n_stages)
-        kx.check(L.kx_gemv_w8_chain_f32(descs, n_stages, state.ptr, state.nbytes, None), "chain")
-        for i in range(n_stages, 4):
-            kx.check(L.kx_gemv_w8_fused_f32(C.byref(descs[i]), None))
-        kx.sync()
-        got = dict(x2=b["x"].numpy(), h=b["h"].numpy(), q=b["q"].numpy(), k=b["kc"].numpy()[pos],
-                   v=b["vc"].numpy()[pos])
-        for name in ("h", "x2", "q", "k", "v"):
-            scale = np.abs(want[name]).max()
-            assert np.abs(got[name] - want[name]).max() <= 3e-5 * scale, (name, n_stages)
-        words = state.numpy(np.uint32, (state.nbytes // 4,))
-        assert words[-64] == 0, "a grid barrier gave up"
-    # preconditions: stage count, state buffer, shapes outside the 16-byte-chunk kernels
-    assert L.kx_gemv_w8_chain_f32(descs, 5, state.ptr, state.nbytes, None) == -1
-    assert L.kx_gemv_w8_chain_f32(descs, 2, None, 0, None) == -3
-    assert L.kx_gemv_w8_chain_f32(descs, 2, state.ptr, 64, None) == -3
-
-
 # ------------------------------- fp32 GEMV ---------------------------------------------------
 def test_gemv_f32_reference_known_answers():
     # test/test_op/test_cu_matmul.cpp:48-106
@@ -359,57 +290,6 @@ def test_mha_decode_device_position_one_workspace_many_launches():
         np.testing.assert_allclose(out.numpy(np.float32, (H, hs)), want, rtol=0, atol=2e-5,
                                    err_msg=f"pos={pos}")
     assert not ws.numpy(np.uint8, (wsb,))[:16384].any()  # tickets are back at zero
-
-
-@pytest.mark.parametrize("H,KVH,hs,S,dim", [(32, 8, 128, 4736, 4096), (32, 8, 64, 700, 2048),
-                                             (28, 4, 128, 600, 3584), (8, 1, 128, 4400, 8192),
-                                             (12, 12, 64, 300, 768), (4, 2, 128, 96, 256)])
-def test_mha_decode_with_fused_output_projection(H, KVH, hs, S, dim):
-    # attention + Wo (+ residual) in one launch against the oracle's mha -> gemv_w8 -> add, at
-    # positions with one split, a few splits and the full grid; position by value and on the device;
-    # one workspace for all launches (its finished-heads counter only ever counts up)
-    rng = np.random.default_rng(H * 1000 + S)
-    kvd, M = KVH * hs, H * hs
-    kc = rng.standard_normal((2, S, kvd)).astype(np.float32)
-    vc = rng.standard_normal((2, S, kvd)).astype(np.float32)
-    _, w, s = rand_w8(rng, dim, M)
-    s *= 30
-    L = kx.lib()
-    dk, dv, dw, dsc = map(kx.Buf.from_numpy, (kc, vc, w, s))
-    wsb = L.kx_attn_workspace_bytes(H, hs)
-    ws = kx.Buf.zeros(wsb, np.uint8)
-    att, y = kx.Buf.zeros(M), kx.Buf.zeros(dim)
-    pos_dev = kx.Buf.zeros(1, np.int32)
-    for i, pos in enumerate((0, 17, 63, 64, 300, S - 1, 5, S // 2)):
-        if pos >= S:
-            continue
-        q = rng.standard_normal(M).astype(np.float32)
-        res = rng.standard_normal(dim).astype(np.float32)
-        dq = kx.Buf.from_numpy(q)
-        y.upload(res)
-        d = kx.GemvDesc(mode=kx.GEMV_PLAIN, group_size=GS, M=M, K=dim, x=att.ptr, w=dw.ptr,
-                        scales=dsc.ptr, y0=y.ptr, residual=y.ptr)
-        on_device = i % 2 == 1
-        pos_dev.upload(np.array([pos], np.int32))
-        kx.check(L.kx_mha_decode_wo_f32(dq.ptr, dk.ptr, dv.ptr, att.ptr, S - 1 if on_device else pos,
-                                        pos_dev.ptr if on_device else None, H, H // KVH, hs, kvd, S, 1,
-                                        C.byref(d), ws.ptr, wsb, None), "kx_mha_decode_wo_f32")
-        kx.sync()
-        want_att = kxo.mha(pos, H, 1, S, kvd, H // KVH, hs, q, kc, vc)
-        np.testing.assert_allclose(att.numpy(), want_att, rtol=0, atol=2e-5, err_msg=f"pos={pos}")
-        want_y = res + kxo.gemv_w8(want_att, w, s, GS, threads=8)
-        tol = 1e-5 * w8_abs_sum(want_att, w, s) + 2e-5 * w8_abs_sum(np.ones_like(want_att), w, s) + 1e-6
-        assert np.all(np.abs(y.numpy() - want_y) <= tol), f"pos={pos}"
-    words = ws.numpy(np.uint8, (wsb,))[:16384].view(np.uint32)
-    assert words[62 * 64] == 0, "a wait for the attention output gave up"
-    assert not words[:KVH * 64].any()     # split tickets are back at zero
-    # preconditions: the projection must read the attention output, plain mode, no norm
-    bad = kx.GemvDesc(mode=kx.GEMV_PLAIN, group_size=GS, M=M, K=dim, x=y.ptr, w=dw.ptr, scales=dsc.ptr,
-                      y0=y.ptr)
-    assert L.kx_mha_decode_wo_f32(dq.ptr, dk.ptr, dv.ptr, att.ptr, 3, None, H, H // KVH, hs, kvd, S, 1,
-                                  C.byref(bad), ws.ptr, wsb, None) == -1
-    assert L.kx_mha_decode_wo_f32(dq.ptr, dk.ptr, dv.ptr, att.ptr, 3, None, H, H // KVH, hs, kvd, S, 1,
-                                  C.byref(d), ws.ptr, 20000, None) == -3
 
 
 def test_mha_decode_forced_rescale_and_no_workspace():

@@ -45,62 +45,6 @@ def main():
                 wsb += 64 * 1024
             ws = kx.Buf.zeros(wsb, np.uint8)
             pos_dev = kx.Buf.from_numpy(np.array([pos], np.int32))
-            if os.environ.get("KX_BENCH_WO"):
-                # attention + output projection: two launches vs the fused launch, Wo rotating over
-                # `layers` distinct matrices (cold weights), residual stream updated in place
-                import ctypes as C
-                dim = M = H * hs
-                wbufs = []
-                for l in range(layers):
-                    w = kx.Buf(dim * M)
-                    sc = kx.Buf(dim * M // 64 * 4)
-                    kx.check(L.kx_fill_hash_i8(w.ptr, dim, M, M, 0, 0, 100 + l, st.ptr))
-                    kx.check(L.kx_fill_hash_f32(sc.ptr, dim, M // 64, M // 64, 0, 0, 200 + l, 1e-4, 3e-4, st.ptr))
-                    wbufs.append((w, sc))
-                y = kx.Buf.zeros(dim)
-                descs = [kx.GemvDesc(mode=0, group_size=64, M=M, K=dim, x=out.ptr, w=w.ptr, scales=sc.ptr,
-                                     y0=y.ptr, residual=y.ptr) for w, sc in wbufs]
-                reps = max(1, 96 // layers)
-
-                def two():
-                    for _ in range(reps):
-                        for l in range(layers):
-                            kx.check(L.kx_mha_decode_dpos_f32(q.ptr, kc.ptr, vc.ptr, out.ptr, pos_dev.ptr,
-                                                              seq - 1, H, H // KVH, hs, kvd, seq, l, ws.ptr,
-                                                              wsb, st.ptr))
-                            kx.check(L.kx_gemv_w8_fused_f32(C.byref(descs[l]), st.ptr))
-
-                def fused():
-                    for _ in range(reps):
-                        for l in range(layers):
-                            kx.check(L.kx_mha_decode_wo_f32(q.ptr, kc.ptr, vc.ptr, out.ptr, seq - 1,
-                                                            pos_dev.ptr, H, H // KVH, hs, kvd, seq, l,
-                                                            C.byref(descs[l]), ws.ptr, wsb, st.ptr))
-                for label, fn in (("attn + Wo, two launches", two), ("attn + Wo, one launch", fused),
-                                  ("attn + Wo, two launches", two)):
-                    us = kx.time_graph(st, fn) / (reps * layers)
-                    print(f"{name} pos={pos:5d} {label:26s} {us:8.2f} us", flush=True)
-                if trace:
-                    kx.check(L.kx_memset(ws.ptr + used, 0, 64 * 1024, st.ptr))
-                    kx.check(L.kx_mha_decode_wo_f32(q.ptr, kc.ptr, vc.ptr, out.ptr, seq - 1, pos_dev.ptr, H,
-                                                    H // KVH, hs, kvd, seq, 0, C.byref(descs[0]), ws.ptr,
-                                                    wsb, st.ptr))
-                    st.sync()
-                    raw = ws.numpy(np.uint8, (wsb,))[used:].view(np.uint64)
-                    nwg = int((raw[0::8] != 0).sum())
-                    t = raw[:nwg * 8].reshape(nwg, 8).astype(np.float64)
-                    t0 = t[:, 0].min()
-                    labels = ["start", "wave 0 tiles done", "all waves done", "partial acked",
-                              "ticket drawn", "merged (last arrivers)", "attention output complete",
-                              "projection rows done"]
-                    print(f"  timeline of one fused launch, {nwg} workgroups:")
-                    for i, lab in enumerate(labels):
-                        col = t[:, i]
-                        col = col[col > 0]
-                        if col.size:
-                            col = (col - t0) / 100.0
-                            print(f"    {lab:26s} n={col.size:4d} min {col.min():6.2f} median "
-                                  f"{np.median(col):6.2f} max {col.max():6.2f}")
             for mode in ("value", "device"):
                 def launch(layer):
                     if mode == "value":
