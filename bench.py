@@ -29,19 +29,40 @@ sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix peak
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_gemv_traffic.json")
+GEMV_SOURCES = [os.path.join(ROOT, "llm-inference-engine_amd", "csrc", f)
+                for f in ("gemv_w8.hip", "gemv_w8.hpp")]
+
+
+def gemv_source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for path in GEMV_SOURCES:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def measured_traffic():
     """HBM bytes per GEMV launch from the committed rocprofv3 --pmc passes over this same command
     (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied by
-    tools/collect_traffic.py).  Counters cannot be read from inside the process, so the figure is
-    the stored one; None if the file is absent."""
+    tools/collect_traffic.py).  Counters cannot be read from inside the process, so the figure is a
+    stored one: the newest profiles/r*_gemv_traffic.json, and only if it was collected from the
+    GEMV kernel source that is in the tree now (the file records the source digest); otherwise
+    (None, reason)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemv_traffic.json")))
+    if not files:
+        return None, "no profiles/r*_gemv_traffic.json"
+    path = files[-1]
+    rel = os.path.relpath(path, ROOT)
     try:
-        with open(TRAFFIC_JSON) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("kernel_source_sha256") != gemv_source_digest():
+            return None, f"{rel} is stale: the GEMV kernel source changed since it was collected"
+        return float(doc["hbm_bytes_per_launch"]), rel
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"{rel}: {e}"
 
 
 def prefill_kernels(kx, shape, tp, T=4096):
@@ -264,6 +285,12 @@ def main():
         kv_bytes = 2 * shape["layer_num"] * (args.context + args.warmup + args.steps // 2) * \
             (shape["dim"] // shape["head_num"] * shape["kv_head_num"]) * (2 if kv16 else 4)
         tok_s = args.steps / elapsed
+        if args.model == "llama-3-8b" and world == 1:
+            traffic, traffic_src = measured_traffic()
+            if traffic is not None:
+                traffic_src += " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, bytes per launch)"
+        else:
+            traffic, traffic_src = None, "collected for the llama-3-8b single-GPU command only"
         line = {
             "metric": "decode tok/s, W8A16 group-quant, batch 1 (W8A16 GEMV HBM GB/s in roofline)",
             "value": tok_s,
@@ -291,9 +318,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic() if args.model == "llama-3-8b" and world == 1 else None,
-                "traffic_source": "profiles/r01_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes, bytes per launch)",
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "gemv_w8_kernel (all W8 GEMV launches of a decode step, per rank)",
                 "launches_timed": n_launch,
                 "algorithmic_bytes_per_launch": gemv_bytes / max(n_launch, 1),

@@ -12,8 +12,22 @@ counters need separate passes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gemv_source_digest():
+    """Digest of the GEMV kernel source the counters were collected from; bench.py reports the
+    stored traffic only while the tree still holds that source."""
+    h = hashlib.sha256()
+    for name in ("gemv_w8.hip", "gemv_w8.hpp"):
+        with open(os.path.join(ROOT, "llm-inference-engine_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def per_kernel(path, counter):
@@ -49,6 +63,7 @@ def main():
     write_total = sum((v["write_bytes_per_launch"] or 0.0) * v["launches_write_pass"] for v in gemv.values())
     doc = {
         "kernel": "gemv_w8_kernel (all instantiations)",
+        "kernel_source_sha256": gemv_source_digest(),
         "launches": n,
         "hbm_bytes_per_launch": fetch_total / n + (write_total / nw if nw else 0.0),
         "fetch_bytes_per_launch": fetch_total / n,
