@@ -327,6 +327,8 @@ def main():
             },
             "decode_hbm_gbps_end_to_end": (bpt + kv_bytes) * tok_s / 1e9 / world,
             "prefill_tok_per_s": args.context / prefill_s if args.context else None,
+            "prefill_note": "second pass over the prompt; fp16 images of the int8 weights are kept "
+                            "from the first pass when they fit a third of free HBM (prefill_weight_cache)",
         }
         if comm is not None:
             if "decode_allreduce_us" in comm:

@@ -51,6 +51,7 @@ int kx_memset(void* ptr, int value, size_t bytes, void* stream);
 int kx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream); /* stream NULL: blocking */
 int kx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int kx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int kx_mem_info(size_t* free_bytes, size_t* total_bytes); /* device memory, hipMemGetInfo */
 int kx_host_alloc_pinned(void** ptr, size_t bytes);
 int kx_host_free_pinned(void* ptr);
 int kx_stream_create(void** stream);
@@ -170,6 +171,10 @@ int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float*
  * workspace (kx_gemm_w8_f16act_workspace_bytes, 256-byte aligned) holds the fp16 weights. */
 #define KX_GEMM_ROUTE_F32 0
 #define KX_GEMM_SWIGLU_F16 1
+/* OR-ed into `mode`: the workspace still holds the fp16 weights that an earlier call with the same
+ * w / scales / mode / M / K left there, so the dequantisation pass is skipped.  A caller with the
+ * memory for it keeps one workspace per matrix and pays the pass once instead of once per call. */
+#define KX_GEMM_WEIGHTS_READY 0x100
 size_t kx_gemm_w8_f16act_workspace_bytes(int32_t M, int32_t K);
 int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales, int32_t group_size,
                          int32_t mode, void* h16, float* y0, int64_t ld0, float* y1, int64_t ld1,

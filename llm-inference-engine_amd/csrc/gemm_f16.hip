@@ -556,16 +556,18 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
                            int32_t group_size, int32_t mode, _Float16* h16, float* y0, int64_t ld0,
                            float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
                            const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
-                           char* ws, hipStream_t s) {
+                           char* ws, hipStream_t s, bool weights_ready = false) {
   using namespace kx;
   _Float16* w16 = reinterpret_cast<_Float16*>(ws);
   float* colf = reinterpret_cast<float*>(ws + align256((size_t)K * M * 2));
   int gs_shift = 0;
   while ((1 << gs_shift) < group_size) ++gs_shift;
   const bool swiglu = mode == KX_GEMM_SWIGLU_F16;
-  hipLaunchKernelGGL(w8_dequant_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, w, scales, w16, colf,
-                     M, K, gs_shift, swiglu ? K / 2 : 0);
-  KX_LAUNCH_CHECK();
+  if (!weights_ready) {
+    hipLaunchKernelGGL(w8_dequant_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, w, scales, w16, colf,
+                       M, K, gs_shift, swiglu ? K / 2 : 0);
+    KX_LAUNCH_CHECK();
+  }
   GemmF16Args a{};
   a.X = x16; a.W = w16; a.colf = colf; a.residual = residual; a.h16 = h16;
   a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
@@ -597,6 +599,8 @@ extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const floa
                                     int32_t T, int32_t M, int32_t K, void* workspace,
                                     size_t workspace_bytes, void* stream) {
   if (!X16 || !w || !scales || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
+  const bool weights_ready = (mode & KX_GEMM_WEIGHTS_READY) != 0;
+  mode &= ~KX_GEMM_WEIGHTS_READY;
   if (!workspace || workspace_bytes < kx_gemm_w8_f16act_workspace_bytes(M, K)) return KX_EWORKSPACE;
   if (!gemm_f16_shape_ok(group_size, M, w, workspace) || (uintptr_t)X16 % 16) return KX_EUNSUPPORTED;
   if (mode == KX_GEMM_SWIGLU_F16) {
@@ -613,7 +617,7 @@ extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const floa
   }
   return gemm_f16act_run(static_cast<const _Float16*>(X16), w, scales, group_size, mode,
                          static_cast<_Float16*>(h16), y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
-                         T, M, K, static_cast<char*>(workspace), (hipStream_t)stream);
+                         T, M, K, static_cast<char*>(workspace), (hipStream_t)stream, weights_ready);
 }
 
 extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float* scales,

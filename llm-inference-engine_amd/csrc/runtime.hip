@@ -110,6 +110,14 @@ extern "C" int kx_stream_sync(void* stream) {
   KX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return KX_OK;
 }
+extern "C" int kx_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  size_t f = 0, t = 0;
+  KX_HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return KX_OK;
+}
+
 extern "C" int kx_device_sync(void) {
   KX_HIP_TRY(hipDeviceSynchronize());
   return KX_OK;

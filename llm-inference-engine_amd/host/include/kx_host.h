@@ -21,6 +21,7 @@ typedef struct kxm_config {
   int32_t tp_size, tp_rank;
   int32_t kv_f16;       /* non-zero: 16-bit (IEEE half) KV cache instead of the reference's fp32 one */
   int32_t qkv_bias;     /* non-zero: q/k/v projections carry fp32 biases (Qwen2 family) */
+  int32_t prefill_weight_cache; /* fp16 weight images for long prompts: 0 per pass, 1 kept, -1 kept if they fit */
 } kxm_config;
 
 const char* kxm_last_error(void);

@@ -62,6 +62,11 @@ struct TransformerConfig {
   // (tools/export_qwen2.py:102-110, qwen2.cpp:306-333); quant files carry none (qwen2.cpp:192-217),
   // so a quant model starts with zero biases and set_qkv_bias() may attach them.
   bool qkv_bias = false;
+  // Long prompts run on fp16 images of the int8 weights (scale applied, one rounding).  0: made
+  // per prompt pass in scratch and dropped; 1: kept per matrix after the first pass (2 bytes per
+  // weight on top of the int8 copy: 15 GB for Llama-3-8B); -1: kept when they fit in a third of
+  // the free device memory at the first long prompt.
+  int32_t prefill_weight_cache = -1;
   // derived (model.cpp:132-134)
   int32_t kv_dim = 0, kv_mul = 0, head_size = 0;
   // per-rank sizes under tensor parallelism
@@ -133,6 +138,9 @@ class LlamaModel {
     void* w = nullptr;       // int8 or fp32 [rows][cols]
     float* s = nullptr;      // scales (quant only)
     float* bias = nullptr;   // optional fp32 [rows]
+    void* w16 = nullptr;     // kept fp16 image for the long-prompt GEMMs (see prefill_weight_cache)
+    size_t w16_bytes = 0;
+    bool w16_ready = false;
     int32_t rows = 0, cols = 0;
     size_t w_bytes() const;
   };
@@ -150,6 +158,9 @@ class LlamaModel {
                              int32_t g_rows, int32_t g_cols, int32_t row0, int32_t rows,
                              int32_t col0, int32_t cols);
   static constexpr int32_t kPrefillChunk = 4096;  // prompt rows per batched pass
+  base::Status reserve_weight_images();
+  void drop_weight_images(bool free_memory);
+  int weight_images_ = 0;  // 0 not decided yet, 1 in use, -1 not available
   base::Status prefill_sequential(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);
   void build_layers();
   base::Status launch_step(void* stream, bool with_events);

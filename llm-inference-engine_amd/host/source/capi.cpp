@@ -39,6 +39,7 @@ void* kxm_create(const kxm_config* c) {
   t.tp_size = c->tp_size < 1 ? 1 : c->tp_size; t.tp_rank = c->tp_rank;
   t.kv_f16 = c->kv_f16 != 0;
   t.qkv_bias = c->qkv_bias != 0;
+  t.prefill_weight_cache = c->prefill_weight_cache;
   auto* m = new model::LlamaModel();
   base::Status s = m->init(t);
   if (!s) {

@@ -131,6 +131,10 @@ base::Status LlamaModel::alloc_linear(Linear& l, int32_t rows, int32_t cols) {
 void LlamaModel::free_linear(Linear& l) {
   if (l.w) kx_free(l.w);
   l.w = nullptr;
+  if (l.w16) kx_free(l.w16);
+  l.w16 = nullptr;
+  l.w16_bytes = 0;
+  l.w16_ready = false;
   dev_free(l.s);
   dev_free(l.bias);
 }
@@ -208,7 +212,52 @@ base::Status LlamaModel::fill_linear_rows(Linear& l, int32_t row_off, int32_t ro
   return base::error::Success();
 }
 
+// fp16 images of every layer matrix for the long-prompt GEMMs, when the policy and the free
+// memory allow; otherwise the GEMMs keep dequantising into scratch.
+base::Status LlamaModel::reserve_weight_images() {
+  if (weight_images_ != 0) return base::error::Success();
+  weight_images_ = -1;
+  if (cfg_.prefill_weight_cache == 0 || !quant_) return base::error::Success();
+  size_t total = 0;
+  for (auto& l : layers_)
+    for (Linear* m : {&l.qkv, &l.wo, &l.w13, &l.w2})
+      total += kx_gemm_w8_f16act_workspace_bytes(m->cols, m->rows) + 256;
+  if (cfg_.prefill_weight_cache < 0) {
+    size_t free_b = 0, total_b = 0;
+    KX_RET(kx_mem_info(&free_b, &total_b));
+    if (total > free_b / 3) return base::error::Success();
+  }
+  for (auto& l : layers_)
+    for (Linear* m : {&l.qkv, &l.wo, &l.w13, &l.w2}) {
+      const size_t need = kx_gemm_w8_f16act_workspace_bytes(m->cols, m->rows);
+      void* p = nullptr;
+      if (kx_malloc(&p, need) != 0) {  // out of memory after all: give the images back
+        drop_weight_images(true);
+        return base::error::Success();
+      }
+      m->w16 = p;
+      m->w16_bytes = need;
+      m->w16_ready = false;
+    }
+  weight_images_ = 1;
+  return base::error::Success();
+}
+
+void LlamaModel::drop_weight_images(bool free_memory) {
+  for (auto& l : layers_)
+    for (Linear* m : {&l.qkv, &l.wo, &l.w13, &l.w2}) {
+      m->w16_ready = false;
+      if (free_memory && m->w16) {
+        kx_free(m->w16);
+        m->w16 = nullptr;
+        m->w16_bytes = 0;
+      }
+    }
+  if (free_memory) weight_images_ = -1;
+}
+
 base::Status LlamaModel::init_synthetic(uint64_t seed) {
+  drop_weight_images(false);
   const TransformerConfig& c = cfg_;
   const ShardPlan& sp = c.plan;
   void* st = hip_->stream;
@@ -278,6 +327,7 @@ base::Status LlamaModel::upload_matrix(Linear& l, int32_t dst_row_off, const voi
 }
 
 base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
+  drop_weight_images(false);
   const TransformerConfig& c = cfg_;
   const size_t hdr = quant_ ? 32 : 28;  // model.cpp:110-114
   if (bytes < hdr) return base::error::ModelParseError("blob shorter than its header");
@@ -887,8 +937,9 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     // per-layer GEMM time of the two forms on the 8B matrices ties at 512..640 rows; the fp16 form
     // also saves the separate SwiGLU pass
     const bool f16_chunk = f16_ok && rows >= 512;
+    if (f16_chunk) ST_RET(reserve_weight_images());
     for (int32_t l = 0; l < c.layer_num; ++l) {
-      const LayerWeights& lw = layers_[l];
+      LayerWeights& lw = layers_[l];
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
       float* krow = c.kv_f16 ? KR : static_cast<float*>(k_ptr) + (size_t)p0 * kl;
       float* vrow = c.kv_f16 ? VR : static_cast<float*>(v_ptr) + (size_t)p0 * kl;
@@ -896,27 +947,36 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
       const float* bk = bq ? bq + ql : nullptr;
       const float* bv = bq ? bq + ql + kl : nullptr;
       if (f16_chunk) {
+        // fp16 weight image: the matrix's own kept one (made by the first pass over it), else scratch
+        auto gemm16 = [&](const void* x16, Linear& lin, int mode, void* h16, float* y0, int64_t ld0,
+                          float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
+                          const float* resid, int64_t ldr, int32_t Mm, int32_t Kk) -> int {
+          void* wsp = lin.w16 ? lin.w16 : gws;
+          const size_t wsb = lin.w16 ? lin.w16_bytes : gemm_ws;
+          const int flag = lin.w16 && lin.w16_ready ? KX_GEMM_WEIGHTS_READY : 0;
+          const int rc = kx_gemm_w8_f16act_ws(x16, static_cast<const int8_t*>(lin.w), lin.s, gs, mode | flag,
+                                              h16, y0, ld0, y1, ld1, y2, ld2, k0, k1, resid, ldr, rows, Mm,
+                                              Kk, wsp, wsb, st);
+          if (rc == 0 && lin.w16) lin.w16_ready = true;
+          return rc;
+        };
         // long chunks keep the GEMM inputs in fp16: the norm and the attention kernel write fp16,
         // SwiGLU runs in the epilogue of the W1|W3 GEMM; XN / ATT / HH are reused as fp16 rows
         KX_RET(kx_rmsnorm_f16out(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
-        KX_RET(kx_gemm_w8_f16act_ws(XN, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs,
-                                    KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
-                                    nullptr, 0, rows, dim, lw.qkv.rows, gws, gemm_ws, st));
+        KX_RET(gemm16(XN, lw.qkv, KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
+                      nullptr, 0, dim, lw.qkv.rows));
         KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
                                 p0, rows, sin_, cos_, st));
         if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
         KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
-        KX_RET(kx_gemm_w8_f16act_ws(ATT, static_cast<const int8_t*>(lw.wo.w), lw.wo.s, gs,
-                                    KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim,
-                                    res, dim, rows, ql, dim, gws, gemm_ws, st));
+        KX_RET(gemm16(ATT, lw.wo, KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim, res,
+                      dim, ql, dim));
         ST_RET(all_reduce(X, (size_t)rows * dim));
         KX_RET(kx_rmsnorm_f16out(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
-        KX_RET(kx_gemm_w8_f16act_ws(XN, static_cast<const int8_t*>(lw.w13.w), lw.w13.s, gs,
-                                    KX_GEMM_SWIGLU_F16, HH, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0,
-                                    nullptr, 0, rows, dim, 2 * hl, gws, gemm_ws, st));
-        KX_RET(kx_gemm_w8_f16act_ws(HH, static_cast<const int8_t*>(lw.w2.w), lw.w2.s, gs,
-                                    KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim,
-                                    res, dim, rows, hl, dim, gws, gemm_ws, st));
+        KX_RET(gemm16(XN, lw.w13, KX_GEMM_SWIGLU_F16, HH, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr,
+                      0, dim, 2 * hl));
+        KX_RET(gemm16(HH, lw.w2, KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim, res,
+                      dim, hl, dim));
         ST_RET(all_reduce(X, (size_t)rows * dim));
         continue;
       }

@@ -36,6 +36,7 @@ SIGNATURES = {
     "kx_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
     "kx_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
     "kx_memcpy_d2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "kx_mem_info": (C.c_int, [C.POINTER(_sz), C.POINTER(_sz)]),
     "kx_host_alloc_pinned": (C.c_int, [C.POINTER(_vp), _sz]),
     "kx_host_free_pinned": (C.c_int, [_vp]),
     "kx_stream_create": (C.c_int, [C.POINTER(_vp)]),

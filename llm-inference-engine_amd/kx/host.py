@@ -18,7 +18,8 @@ class Config(C.Structure):
                 ("head_num", C.c_int32), ("kv_head_num", C.c_int32), ("vocab_size", C.c_int32),
                 ("seq_len", C.c_int32), ("group_size", C.c_int32), ("rope_variant", C.c_int32),
                 ("rope_theta", C.c_float), ("rms_eps", C.c_float), ("tp_size", C.c_int32),
-                ("tp_rank", C.c_int32), ("kv_f16", C.c_int32), ("qkv_bias", C.c_int32)]
+                ("tp_rank", C.c_int32), ("kv_f16", C.c_int32), ("qkv_bias", C.c_int32),
+                ("prefill_weight_cache", C.c_int32)]
 
 
 # the model shapes named by the benchmark configs
@@ -92,9 +93,10 @@ def _p(a):
 
 class Model:
     def __init__(self, seq_len, group_size=64, tp_size=1, tp_rank=0, kv_f16=False, qkv_bias=False,
-                 **shape):
+                 prefill_weight_cache=-1, **shape):
         self.cfg = Config(seq_len=seq_len, group_size=group_size, tp_size=tp_size, tp_rank=tp_rank,
-                          kv_f16=1 if kv_f16 else 0, qkv_bias=1 if qkv_bias else 0, **shape)
+                          kv_f16=1 if kv_f16 else 0, qkv_bias=1 if qkv_bias else 0,
+                          prefill_weight_cache=prefill_weight_cache, **shape)
         self.h = hlib().kxm_create(C.byref(self.cfg))
         if not self.h:
             raise KxError("kxm_create failed: " + hlib().kxm_last_error().decode())

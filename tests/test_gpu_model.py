@@ -395,6 +395,31 @@ def test_batched_prefill_vs_oracle_rows(shape, n):
         assert mm.history(n + 1)[n] == tok
 
 
+def test_kept_fp16_weight_images_give_the_same_prompt_results():
+    # prefill_weight_cache: the fp16 images of the int8 weights are made per pass (0) or kept after
+    # the first pass (1); same kernels on the same images, so the results are bit-identical, also on
+    # the second prompt (which skips the dequantisation) and after the weights are replaced
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    rng = np.random.default_rng(8)
+    p1 = rng.integers(0, 1000, 600).astype(np.int32)
+    p2 = rng.integers(0, 1000, 520).astype(np.int32)
+    outs = {}
+    for cache in (0, 1):
+        m = host.Model(seq_len=640, group_size=GS, prefill_weight_cache=cache, **shape)
+        m.init_synthetic(31)
+        a = m.prefill(p1)
+        b = m.prefill(p2)           # images ready: no dequantisation pass
+        ka, va = m.read_kv(1, 520)
+        m.init_synthetic(32)        # new weights: kept images must not be reused
+        c = m.prefill(p2)
+        outs[cache] = (a, b, ka, va, c)
+        m.close()
+    for x, y in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(x, y)
+    assert np.abs(outs[1][1] - outs[1][4]).max() > 0
+
+
 def test_tp_shards_are_slices_of_the_unsharded_weights():
     # column-parallel rows / row-parallel columns as the shard plan says, for synthetic weights
     shape = dict(dim=512, hidden_dim=1024, layer_num=1, head_num=8, kv_head_num=2, vocab_size=256,
