@@ -104,6 +104,9 @@ class LlamaModel {
   // Test rig: the ranks of a tensor-parallel model as objects of one process (one thread each),
   // summing through a host rendezvous instead of RCCL.  Eager launches only.
   void join_loopback(std::shared_ptr<base::LoopbackGroup> group) { loop_ = std::move(group); }
+  // Row sub-blocks per row-parallel GEMM of a long prompt pass under tensor parallelism (>= 1;
+  // 1 = one reduce after the whole GEMM, nothing overlapped).
+  void set_prefill_subblocks(int32_t n) { prefill_subblocks_ = n < 1 ? 1 : n; }
 
   // ---- reference-structured path ----
   base::Status forward_layers(int32_t token, int32_t pos, float* logits_host);
@@ -168,6 +171,10 @@ class LlamaModel {
                     float* y1, float* y2, int32_t k0, int32_t k1, const float* residual,
                     void* stream);
   base::Status all_reduce(float* buf, size_t count);
+  base::Status all_reduce_begin(float* buf, size_t count);
+  base::Status all_reduce_end();
+  bool comm_pending_ = false;
+  int32_t prefill_subblocks_ = 4;  // row sub-blocks of a row-parallel prompt GEMM (reduce j beside GEMM j+1)
 
   TransformerConfig cfg_;
   bool quant_ = false;

@@ -86,6 +86,11 @@ int kxm_init_comm(void* m, const void* id128) {
   if (id128) std::memcpy(id.data(), id128, id.size());
   return done(M(m)->init_comm(id128 ? &id : nullptr));
 }
+int kxm_set_prefill_subblocks(void* m, int32_t n) {
+  if (!m) return -1;
+  M(m)->set_prefill_subblocks(n);
+  return 0;
+}
 void* kxm_loopback_create(int32_t ranks) {
   if (ranks < 1) return nullptr;
   return new std::shared_ptr<base::LoopbackGroup>(std::make_shared<base::LoopbackGroup>(ranks));

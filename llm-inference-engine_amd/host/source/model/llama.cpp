@@ -738,14 +738,29 @@ base::Status LlamaModel::gemv(const Linear& l, int mode, const float* x, const f
 }
 
 base::Status LlamaModel::all_reduce(float* buf, size_t count) {
-  if (loop_) return loop_->all_reduce(cfg_.tp_rank, buf, count, hip_->stream);
+  ST_RET(all_reduce_begin(buf, count));
+  return all_reduce_end();
+}
+
+// The two halves of the side-stream all-reduce (matmul.cpp:93-116, events reused): begin() makes
+// the comm stream wait for everything the compute stream has been given so far and queues the
+// collective there; the compute stream is NOT held, so what it is given next runs beside the
+// collective.  end() makes the compute stream wait for every collective queued since.
+base::Status LlamaModel::all_reduce_begin(float* buf, size_t count) {
+  if (loop_) return loop_->all_reduce(cfg_.tp_rank, buf, count, hip_->stream);  // test rig: in line
   if (cfg_.tp_size <= 1 && !comm_ready_) return base::error::Success();
   if (!comm_ready_) return base::error::InternalError("tensor-parallel model without init_comm()");
   auto comm = base::RcclHandler::get_instance();
-  // all-reduce on the side stream between two reused events (matmul.cpp:93-116)
   KX_RET(kx_event_record(hip_->compute_done, hip_->stream));
   KX_RET(kx_stream_wait_event(hip_->comm_stream, hip_->compute_done));
   ST_RET(comm->AllReduce(buf, buf, count, base::DataType::kDataTypeFp32, hip_->comm_stream));
+  comm_pending_ = true;
+  return base::error::Success();
+}
+
+base::Status LlamaModel::all_reduce_end() {
+  if (!comm_pending_) return base::error::Success();
+  comm_pending_ = false;
   KX_RET(kx_event_record(hip_->comm_done, hip_->comm_stream));
   KX_RET(kx_stream_wait_event(hip_->stream, hip_->comm_done));
   return base::error::Success();
@@ -950,15 +965,35 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
         // fp16 weight image: the matrix's own kept one (made by the first pass over it), else scratch
         auto gemm16 = [&](const void* x16, Linear& lin, int mode, void* h16, float* y0, int64_t ld0,
                           float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
-                          const float* resid, int64_t ldr, int32_t Mm, int32_t Kk) -> int {
+                          const float* resid, int64_t ldr, int32_t Mm, int32_t Kk, int32_t T_ = 0,
+                          bool scratch_holds_it = false) -> int {
           void* wsp = lin.w16 ? lin.w16 : gws;
           const size_t wsb = lin.w16 ? lin.w16_bytes : gemm_ws;
-          const int flag = lin.w16 && lin.w16_ready ? KX_GEMM_WEIGHTS_READY : 0;
-          const int rc = kx_gemm_w8_f16act_ws(x16, static_cast<const int8_t*>(lin.w), lin.s, gs, mode | flag,
-                                              h16, y0, ld0, y1, ld1, y2, ld2, k0, k1, resid, ldr, rows, Mm,
-                                              Kk, wsp, wsb, st);
+          const bool ready = lin.w16 ? lin.w16_ready : scratch_holds_it;
+          const int rc = kx_gemm_w8_f16act_ws(x16, static_cast<const int8_t*>(lin.w), lin.s, gs,
+                                              mode | (ready ? KX_GEMM_WEIGHTS_READY : 0), h16, y0, ld0, y1,
+                                              ld1, y2, ld2, k0, k1, resid, ldr, T_ > 0 ? T_ : rows, Mm, Kk,
+                                              wsp, wsb, st);
           if (rc == 0 && lin.w16) lin.w16_ready = true;
           return rc;
+        };
+        // Row-parallel product (Wo, W2) under tensor parallelism: the rows go through the GEMM in
+        // sub-blocks, and the all-reduce of sub-block j runs on the side stream while the GEMM of
+        // sub-block j+1 runs here; only the last sub-block's reduce is waited for with nothing beside it.
+        auto row_parallel = [&](const void* x16, int64_t x_ld_halves, Linear& lin, int32_t Mm) -> base::Status {
+          const bool reducing = loop_ || comm_ready_ || c.tp_size > 1;
+          int32_t nsub = reducing ? prefill_subblocks_ : 1;
+          if (nsub > rows / 1024) nsub = rows / 1024;
+          if (nsub < 1) nsub = 1;
+          const int32_t per = ((rows + nsub - 1) / nsub + 255) / 256 * 256;
+          for (int32_t r0 = 0, j = 0; r0 < rows; r0 += per, ++j) {
+            const int32_t nr = rows - r0 < per ? rows - r0 : per;
+            const char* xin = static_cast<const char*>(x16) + (size_t)r0 * x_ld_halves * 2;
+            KX_RET(gemm16(xin, lin, KX_GEMM_ROUTE_F32, nullptr, X + (size_t)r0 * dim, dim, nullptr, 0, nullptr,
+                          0, dim, dim, res ? res + (size_t)r0 * dim : nullptr, dim, Mm, dim, nr, j > 0));
+            ST_RET(all_reduce_begin(X + (size_t)r0 * dim, (size_t)nr * dim));
+          }
+          return all_reduce_end();
         };
         // long chunks keep the GEMM inputs in fp16: the norm and the attention kernel write fp16,
         // SwiGLU runs in the epilogue of the W1|W3 GEMM; XN / ATT / HH are reused as fp16 rows
@@ -969,15 +1004,11 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
                                 p0, rows, sin_, cos_, st));
         if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
         KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
-        KX_RET(gemm16(ATT, lw.wo, KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim, res,
-                      dim, ql, dim));
-        ST_RET(all_reduce(X, (size_t)rows * dim));
+        ST_RET(row_parallel(ATT, ql, lw.wo, ql));
         KX_RET(kx_rmsnorm_f16out(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
         KX_RET(gemm16(XN, lw.w13, KX_GEMM_SWIGLU_F16, HH, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr,
                       0, dim, 2 * hl));
-        KX_RET(gemm16(HH, lw.w2, KX_GEMM_ROUTE_F32, nullptr, X, dim, nullptr, 0, nullptr, 0, dim, dim, res,
-                      dim, hl, dim));
-        ST_RET(all_reduce(X, (size_t)rows * dim));
+        ST_RET(row_parallel(HH, hl, lw.w2, hl));
         continue;
       }
       KX_RET(kx_rmsnorm_f32(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));

@@ -158,6 +158,11 @@ class Model:
         buf = np.frombuffer(id128, np.uint8).copy() if id128 is not None else None
         hcheck(hlib().kxm_init_comm(self.h, _p(buf)), "kxm_init_comm")
 
+    def set_prefill_subblocks(self, n):
+        L = hlib()
+        L.kxm_set_prefill_subblocks.argtypes = [_vp, _i32]
+        hcheck(L.kxm_set_prefill_subblocks(self.h, int(n)), "kxm_set_prefill_subblocks")
+
     def join_loopback(self, group):
         hcheck(hlib().kxm_join_loopback(self.h, group), "kxm_join_loopback")
 

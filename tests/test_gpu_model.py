@@ -463,6 +463,57 @@ def test_single_rank_communicator_runs_the_allreduce_path():
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
 
 
+def test_prompt_pass_overlaps_reduces_with_the_next_sub_block():
+    # Under tensor parallelism a long prompt pass sends Wo and W2 through the GEMM in row
+    # sub-blocks; the reduce of one sub-block is queued on the side stream while the next
+    # sub-block's GEMM runs.  With a one-rank RCCL communicator (the collectives are identities)
+    # the mechanism runs for real -- two streams, two events, several collectives in flight per
+    # GEMM -- and must give exactly what the serial form and the communicator-free model give.
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    toks = np.random.default_rng(4).integers(0, 1000, 2300).astype(np.int32)
+    outs = []
+    for comm, nsub in ((False, 4), (True, 1), (True, 4), (True, 3)):
+        m = host.Model(seq_len=2400, group_size=GS, **shape)
+        m.init_synthetic(9)
+        if comm:
+            m.init_comm(host.comm_unique_id())
+        m.set_prefill_subblocks(nsub)
+        last = m.prefill(toks)
+        k, v = m.read_kv(1, len(toks))
+        m.decode(4, use_graph=True)
+        outs.append((last, k, v, m.history(len(toks) + 5)))
+        m.close()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_tensor_parallel_prompt_sub_blocks_equal_single_rank():
+    # the same with real partial sums: two ranks in this process (host rendezvous), 2300 rows in
+    # sub-blocks of 768/1024 rows, against the unsharded model
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    toks = np.random.default_rng(6).integers(0, 700, 2300).astype(np.int32)
+    one = host.Model(seq_len=2400, group_size=GS, **shape)
+    one.init_synthetic(21)
+    want = one.prefill(toks)
+    for nsub in (1, 3):
+        group = host.loopback_create(2)
+        ranks = [host.Model(seq_len=2400, group_size=GS, tp_size=2, tp_rank=r, **shape) for r in range(2)]
+        for m in ranks:
+            m.init_synthetic(21)
+            m.join_loopback(group)
+            m.set_prefill_subblocks(nsub)
+        got = _run_ranks(ranks, lambda r, m: m.prefill(toks))
+        np.testing.assert_array_equal(got[0], got[1])
+        assert np.abs(got[0] - want).max() <= 2e-3 * np.abs(want).max()
+        for m in ranks:
+            m.close()
+        host.loopback_destroy(group)
+    one.close()
+
+
 # ---------------- 16-bit KV cache -------------------------------------------------------------------
 @pytest.mark.parametrize("n", [40, 530])
 def test_kv16_model_tracks_the_fp32_cache_model(n):
