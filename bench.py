@@ -237,6 +237,7 @@ def main():
     prefill_s = time.perf_counter() - t0
 
     use_graph = not args.no_graph
+    graph_note = None
     try:
         model.decode(max(args.warmup, 2), use_graph=use_graph)  # untimed; also captures the graph
     except kx.KxError as e:
@@ -246,6 +247,7 @@ def main():
         print(f"[bench] graph replay unavailable ({e}); falling back to eager launches",
               file=sys.stderr, flush=True)
         use_graph = False
+        graph_note = f"graph capture failed, eager launches timed: {e}"
         model.decode(max(args.warmup, 2), use_graph=False)
     fence()
     t0 = time.perf_counter()
@@ -332,6 +334,7 @@ def main():
                 "parallelism": f"tp{world}",
                 "context": args.context,
                 "graph_replay": use_graph,
+                "graph_note": graph_note,
                 "final_pos": pos,
             },
             "roofline": {

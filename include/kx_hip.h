@@ -337,6 +337,19 @@ int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev, int32
                        int32_t* history_dev, int32_t history_len, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* The same step end for a classifier whose rows are split over tensor-parallel ranks (no
+ * reference counterpart: the reference never shards, nccl_handler.cpp:60-80).  Each rank turns its
+ * slice of the logits (`n` values, global index of the first = index_base) into one candidate
+ * {value, global index as fp32}; the caller all-gathers the candidates ([ranks][2] floats) and
+ * kx_decode_step_end_candidates picks the winner (largest value, lowest index on ties -- the first
+ * maximum of the unsharded logits) and does the bookkeeping of kx_decode_step_end.  Indices must
+ * stay below 2^24.  `workspace`: kx_step_workspace_bytes(). */
+int kx_argmax_candidate_f32(const float* logits, int32_t n, int32_t index_base, float* candidate,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int kx_decode_step_end_candidates(const float* candidates, int32_t ranks, int32_t* token_dev,
+                                  int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
+                                  void* stream);
+
 /* Seeded synthetic tensors generated on the device (the benchmarks run on random-init weights;
  * the reference reads real checkpoints through mmap, model.cpp:93-115).  dst is a dense
  * [rows][cols] slice whose element (i, j) is element (row0+i, col0+j) of a global matrix with

@@ -317,6 +317,42 @@ __global__ __launch_bounds__(256) void decode_step_end_kernel(const float* __res
   }
 }
 
+// Tensor-parallel greedy pick over a row-split classifier: every rank reduces ITS slice of the
+// logits to one candidate {value, global index (exact in fp32: < 2^24)}, the candidates are
+// all-gathered, and every rank picks the same winner (largest value, lowest index on ties: the
+// first maximum of the unsharded vector, argmax_sampler.cpp:6-8).
+__global__ __launch_bounds__(256) void argmax_candidate_kernel(const float* __restrict__ pv,
+                                                               const int32_t* __restrict__ pi,
+                                                               int nparts, int index_base,
+                                                               float* __restrict__ cand) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) argmax_merge(best, bi, pv[i], pi[i]);
+  block_argmax(best, bi, sv, si);
+  if (threadIdx.x == 0) {
+    cand[0] = best;
+    cand[1] = bi == 0x7fffffff ? -1.0f : (float)(index_base + bi);
+  }
+}
+
+__global__ void step_end_candidates_kernel(const float* __restrict__ cands, int ranks, int32_t* token,
+                                           int32_t* pos, int32_t* history, int history_len) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int r = 0; r < ranks; ++r) {
+    const float idx = cands[2 * r + 1];
+    if (idx >= 0.f) argmax_merge(best, bi, cands[2 * r], (int)idx);
+  }
+  if (bi == 0x7fffffff) bi = 0;
+  const int p = *pos;
+  if (history && p + 1 < history_len) history[p + 1] = bi;
+  *token = bi;
+  *pos = p + 1;
+}
+
 // ---- seeded synthetic tensors, generated on the device ----
 // Element (i, j) of the GLOBAL matrix gets a value that depends only on (seed, i*ld + j), so a
 // tensor-parallel shard holds exactly the slice of the unsharded tensor.
@@ -464,6 +500,33 @@ extern "C" int kx_decode_step_end(const float* logits, int32_t n, int32_t* token
   KX_LAUNCH_CHECK();
   hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pv, pi,
                      blocks, token_dev, pos_dev, history_dev, history_len);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_argmax_candidate_f32(const float* logits, int32_t n, int32_t index_base,
+                                       float* candidate, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  if (!logits || n <= 0 || index_base < 0 || !candidate) return KX_EINVAL;
+  if ((int64_t)index_base + n > (1 << 24)) return KX_EUNSUPPORTED;  // indices travel as fp32
+  if (!workspace || workspace_bytes < kStepBlocks * 8) return KX_EWORKSPACE;
+  float* pv = static_cast<float*>(workspace);
+  int32_t* pi = reinterpret_cast<int32_t*>(pv + kStepBlocks);
+  const int blocks = n < kStepBlocks * 256 ? (n + 255) / 256 : kStepBlocks;
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, n,
+                     pv, pi);
+  hipLaunchKernelGGL(argmax_candidate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pv, pi,
+                     blocks, index_base, candidate);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_decode_step_end_candidates(const float* candidates, int32_t ranks,
+                                             int32_t* token_dev, int32_t* pos_dev,
+                                             int32_t* history_dev, int32_t history_len, void* stream) {
+  if (!candidates || ranks <= 0 || !token_dev || !pos_dev) return KX_EINVAL;
+  hipLaunchKernelGGL(step_end_candidates_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, candidates,
+                     ranks, token_dev, pos_dev, history_dev, history_len);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

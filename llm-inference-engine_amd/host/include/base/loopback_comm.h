@@ -21,6 +21,9 @@ class LoopbackGroup {
   int size() const { return n_; }
   // In-place sum over the ranks' buffers of `count` floats, in rank order; every rank calls it.
   Status all_reduce(int rank, float* buf, size_t count, void* stream);
+  // In-place all-gather: rank r's `count` floats sit at buf + r*count; afterwards every rank's
+  // buffer holds all the slices.
+  Status all_gather(int rank, float* buf, size_t count, void* stream);
 
  private:
   void arrive();

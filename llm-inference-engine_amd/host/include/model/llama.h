@@ -71,6 +71,11 @@ struct TransformerConfig {
   int32_t kv_dim = 0, kv_mul = 0, head_size = 0;
   // per-rank sizes under tensor parallelism
   int32_t q_dim_local = 0, kv_dim_local = 0, hidden_local = 0, head_local = 0, kv_head_local = 0;
+  // classifier: rows [vocab_row0, vocab_row0 + vocab_local) on this rank.  Split over the ranks
+  // when the vocabulary divides (each rank streams 1/tp of the largest matrix of the model; the
+  // greedy pick travels as one {value, index} candidate per rank), else replicated.
+  int32_t vocab_local = 0, vocab_row0 = 0;
+  bool cls_split = false;
   ShardPlan plan;
   base::Status finalize();
 };
@@ -173,6 +178,11 @@ class LlamaModel {
   base::Status all_reduce(float* buf, size_t count);
   base::Status all_reduce_begin(float* buf, size_t count);
   base::Status all_reduce_end();
+  base::Status all_gather(float* buf, size_t count_per_rank);  // in place, slice r at buf + r*count
+  // final norm + classifier on `x_row`, then the greedy pick and the step bookkeeping
+  base::Status classify_and_pick(const float* x_row, bool write_history, void* stream);
+  base::Status gather_logits();  // split classifier: every rank's slice into logits_ (a collective)
+  float* cand_ = nullptr;        // [1 + tp][2]: this rank's candidate, then everyone's
   bool comm_pending_ = false;
   int32_t prefill_subblocks_ = 4;  // row sub-blocks of a row-parallel prompt GEMM (reduce j beside GEMM j+1)
 

@@ -36,4 +36,17 @@ Status LoopbackGroup::all_reduce(int rank, float* buf, size_t count, void* strea
   return rc == 0 ? error::Success() : error::InternalError("loopback all-reduce failed");
 }
 
+Status LoopbackGroup::all_gather(int rank, float* buf, size_t count, void* stream) {
+  if (rank < 0 || rank >= n_ || !buf) return error::InvalidArgument("bad loopback rank/buffer");
+  int rc = kx_stream_sync(stream);
+  bufs_[rank] = buf;
+  arrive();  // every rank's own slice is complete and published
+  for (int r = 0; r < n_ && rc == 0; ++r)
+    if (r != rank)
+      rc = kx_memcpy_d2d(buf + (size_t)r * count, bufs_[r] + (size_t)r * count, count * sizeof(float), stream);
+  if (rc == 0) rc = kx_stream_sync(stream);
+  arrive();  // nobody overwrites a slice another rank still reads
+  return rc == 0 ? error::Success() : error::InternalError("loopback all-gather failed");
+}
+
 }  // namespace base

@@ -71,6 +71,9 @@ base::Status TransformerConfig::finalize() {
   q_dim_local = plan.q_dim_local;
   kv_dim_local = plan.kv_dim_local;
   hidden_local = plan.hidden_local;
+  cls_split = tp_size > 1 && vocab_size % tp_size == 0 && vocab_size < (1 << 24);
+  vocab_local = cls_split ? vocab_size / tp_size : vocab_size;
+  vocab_row0 = cls_split ? tp_rank * vocab_local : 0;
   if (group_size > 0) {
     // quant groups run along the input dimension; row-parallel shards must cut on group borders
     if (dim % group_size || hidden_dim % group_size || q_dim_local % group_size ||
@@ -115,6 +118,7 @@ LlamaModel::~LlamaModel() {
   dev_free(sin_); dev_free(cos_);
   dev_free(token_dev_); dev_free(pos_dev_); dev_free(history_dev_); dev_free(step_ws_);
   dev_free(pf_);
+  dev_free(cand_);
 }
 
 base::Status LlamaModel::alloc_linear(Linear& l, int32_t rows, int32_t cols) {
@@ -158,7 +162,8 @@ base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
     ST_RET(dev_alloc(l.attn_norm, dim));
     ST_RET(dev_alloc(l.ffn_norm, dim));
   }
-  ST_RET(alloc_linear(cls_, cfg_.vocab_size, dim));
+  ST_RET(alloc_linear(cls_, cfg_.vocab_local, dim));
+  ST_RET(dev_alloc(cand_, 2 * (size_t)(1 + cfg_.tp_size)));
   ST_RET(dev_alloc(emb_, (size_t)cfg_.vocab_size * dim));
   ST_RET(dev_alloc(final_norm_, dim));
 
@@ -289,7 +294,7 @@ base::Status LlamaModel::init_synthetic(uint64_t seed) {
     KX_RET(kx_memcpy_h2d(lw.attn_norm, ones.data(), c.dim * sizeof(float), nullptr));
     KX_RET(kx_memcpy_h2d(lw.ffn_norm, ones.data(), c.dim * sizeof(float), nullptr));
   }
-  ST_RET(fill_linear_rows(cls_, 0, c.vocab_size, c.dim, 0, 0, seed * 1000003ull + 7777));
+  ST_RET(fill_linear_rows(cls_, 0, c.vocab_local, c.dim, c.vocab_row0, 0, seed * 1000003ull + 7777));
   KX_RET(kx_fill_hash_f32(emb_, c.vocab_size, c.dim, c.dim, 0, 0, seed * 1000003ull + 8888, -1.0f,
                           1.0f, st));
   KX_RET(kx_memcpy_h2d(final_norm_, ones.data(), c.dim * sizeof(float), nullptr));
@@ -458,7 +463,7 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
     final_norm = reinterpret_cast<const float*>(p); p += dim * 4;
   }
   if (p > end) return base::error::ModelParseError("blob truncated");
-  ST_RET(upload_matrix(cls_, 0, cls_w, cls_s, V, dim, 0, V, 0, dim));
+  ST_RET(upload_matrix(cls_, 0, cls_w, cls_s, V, dim, c.vocab_row0, c.vocab_local, 0, dim));
   KX_RET(kx_memcpy_h2d(emb_, emb, V * dim * 4, nullptr));
   for (size_t l = 0; l < L; ++l) {
     KX_RET(kx_memcpy_h2d(layers_[l].attn_norm, reinterpret_cast<const uint8_t*>(attn_norm) + l * dim * 4,
@@ -597,7 +602,7 @@ void LlamaModel::build_layers() {
     R.w3.push_back(make(lw.w13, c.hidden_local, c.hidden_local, false));
     R.w2.push_back(make(lw.w2, 0, c.dim, true));
   }
-  R.cls = make(cls_, 0, c.vocab_size, false);
+  R.cls = make(cls_, 0, c.vocab_local, false);
   auto norm = [&](float* w) {
     auto n = std::make_shared<op::RmsNormLayer>(kHip, c.dim);
     n->set_cuda_config(hip_);
@@ -638,7 +643,7 @@ void LlamaModel::build_layers() {
   R.buffers[B::kW3Output] = f32({c.hidden_local}, h3_);
   R.buffers[B::kSinCache] = f32({c.head_size * c.seq_len}, sin_);
   R.buffers[B::kCosCache] = f32({c.head_size * c.seq_len}, cos_);
-  R.buffers[B::kForwardOutput] = f32({c.vocab_size}, logits_);
+  R.buffers[B::kForwardOutput] = f32({c.vocab_local}, logits_ + c.vocab_row0);
   R.buffers[B::kKeyCache] = f32({c.layer_num, c.seq_len, c.kv_dim_local},
                                 static_cast<float*>(kv_->get_raw_buffer_k()));
   R.buffers[B::kValueCache] = f32({c.layer_num, c.seq_len, c.kv_dim_local},
@@ -695,6 +700,7 @@ base::Status LlamaModel::forward_layers(int32_t token, int32_t pos, float* logit
   // cls_logits (:790-799)
   ST_RET(R.rmsnorm[2 * c.layer_num]->forward(x, x));
   ST_RET(R.cls->forward(x, buf[B::kForwardOutput]));
+  ST_RET(gather_logits());
   if (logits_host) {
     KX_RET(kx_stream_sync(hip_->stream));
     KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)c.vocab_size * 4, nullptr));
@@ -795,13 +801,50 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
     ST_RET(gemv(lw.w2, KX_GEMV_PLAIN, h_, nullptr, x_, nullptr, nullptr, 0, 0, res, st));
     if (all) ST_RET(all_reduce(x_, c.dim));
   }
-  ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_, final_norm_, logits_, nullptr, nullptr, 0, 0, nullptr, st));
-  if (!all) return base::error::Success();
+  if (!all) return gemv(cls_, KX_GEMV_PLAIN, x_, final_norm_, logits_ + c.vocab_row0, nullptr, nullptr, 0,
+                        0, nullptr, st);
   // greedy sample; a prompt step keeps the given next token and only advances the position
-  KX_RET(kx_decode_step_end(logits_, c.vocab_size, token_dev_, pos_dev_,
-                            sample ? history_dev_ : nullptr, c.seq_len + 1, step_ws_,
-                            kx_step_workspace_bytes(), st));
+  return classify_and_pick(x_, sample, st);
+}
+
+base::Status LlamaModel::classify_and_pick(const float* x_row, bool write_history, void* st) {
+  const TransformerConfig& c = cfg_;
+  float* local = logits_ + c.vocab_row0;
+  ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_row, final_norm_, local, nullptr, nullptr, 0, 0, nullptr, st));
+  int32_t* hist = write_history ? history_dev_ : nullptr;
+  // a communicator of one rank takes the candidate route too, so that route (its extra launches
+  // and its collective) can be exercised, graph capture included, on a single GPU
+  if (!c.cls_split && !(comm_ready_ && c.tp_size == 1)) {
+    KX_RET(kx_decode_step_end(local, c.vocab_local, token_dev_, pos_dev_, hist, c.seq_len + 1, step_ws_,
+                              kx_step_workspace_bytes(), st));
+    return base::error::Success();
+  }
+  // this rank's best {value, global index} into slot (1 + rank); all-gather the slots; same pick everywhere
+  float* slots = cand_ + 2;
+  KX_RET(kx_argmax_candidate_f32(local, c.vocab_local, c.vocab_row0, slots + 2 * c.tp_rank, step_ws_,
+                                 kx_step_workspace_bytes(), st));
+  ST_RET(all_gather(slots, 2));
+  KX_RET(kx_decode_step_end_candidates(slots, c.tp_size, token_dev_, pos_dev_, hist, c.seq_len + 1, st));
   return base::error::Success();
+}
+
+base::Status LlamaModel::all_gather(float* buf, size_t count) {
+  if (loop_) return loop_->all_gather(cfg_.tp_rank, buf, count, hip_->stream);
+  if (cfg_.tp_size <= 1 && !comm_ready_) return base::error::Success();
+  if (!comm_ready_) return base::error::InternalError("tensor-parallel model without init_comm()");
+  auto comm = base::RcclHandler::get_instance();
+  KX_RET(kx_event_record(hip_->compute_done, hip_->stream));
+  KX_RET(kx_stream_wait_event(hip_->comm_stream, hip_->compute_done));
+  ST_RET(comm->AllGather(buf + (size_t)cfg_.tp_rank * count, buf, count, base::DataType::kDataTypeFp32,
+                         hip_->comm_stream));
+  KX_RET(kx_event_record(hip_->comm_done, hip_->comm_stream));
+  KX_RET(kx_stream_wait_event(hip_->stream, hip_->comm_done));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::gather_logits() {
+  if (!cfg_.cls_split) return base::error::Success();
+  return all_gather(logits_, (size_t)cfg_.vocab_local);
 }
 
 base::Status LlamaModel::set_state(int32_t token, int32_t pos) {
@@ -816,6 +859,7 @@ base::Status LlamaModel::set_state(int32_t token, int32_t pos) {
 base::Status LlamaModel::step_logits(int32_t token, int32_t pos, float* logits_host) {
   ST_RET(set_state(token, pos));
   ST_RET(launch_step(hip_->stream, true));
+  ST_RET(gather_logits());
   KX_RET(kx_stream_sync(hip_->stream));
   if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)cfg_.vocab_size * 4, nullptr));
   return base::error::Success();
@@ -860,6 +904,7 @@ base::Status LlamaModel::prefill_sequential(const int32_t* tokens, int32_t n, in
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
   KX_RET(kx_memcpy_h2d(pos_dev_, &pos0, 4, nullptr));
   for (int32_t i = 0; i < n; ++i) ST_RET(launch_step(hip_->stream, false));
+  ST_RET(gather_logits());
   KX_RET(kx_stream_sync(hip_->stream));
   // leave the state ready for decode(): the sampled token of the last prompt row
   int32_t next = 0;
@@ -1037,10 +1082,8 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   // classifier on the last row only (cls_logits, llama3.cpp:790-799), then the greedy pick
   const int32_t last_pos = pos0 + n - 1;
   KX_RET(kx_memcpy_h2d(pos_dev_, &last_pos, 4, st));
-  ST_RET(gemv(cls_, KX_GEMV_PLAIN, X + (size_t)(rows - 1) * dim, final_norm_, logits_, nullptr,
-              nullptr, 0, 0, nullptr, st));
-  KX_RET(kx_decode_step_end(logits_, c.vocab_size, token_dev_, pos_dev_, history_dev_,
-                            c.seq_len + 1, step_ws_, kx_step_workspace_bytes(), st));
+  ST_RET(classify_and_pick(X + (size_t)(rows - 1) * dim, true, st));
+  ST_RET(gather_logits());
   KX_RET(kx_stream_sync(st));
   if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)c.vocab_size * 4, nullptr));
   return base::error::Success();

@@ -105,6 +105,8 @@ class Model:
         self.kv_dim_local = c.kv_head_num // tp_size * self.head_size
         self.q_dim_local = c.head_num // tp_size * self.head_size
         self.hidden_local = c.hidden_dim // tp_size
+        # the classifier's rows are split over the ranks when the vocabulary divides
+        self.vocab_local = c.vocab_size // tp_size if c.vocab_size % tp_size == 0 else c.vocab_size
 
     def close(self):
         if self.h:
@@ -135,7 +137,7 @@ class Model:
         shapes = {"wq": (self.q_dim_local, c.dim), "wk": (self.kv_dim_local, c.dim),
                   "wv": (self.kv_dim_local, c.dim), "wo": (c.dim, self.q_dim_local),
                   "w1": (self.hidden_local, c.dim), "w3": (self.hidden_local, c.dim),
-                  "w2": (c.dim, self.hidden_local), "cls": (c.vocab_size, c.dim)}
+                  "w2": (c.dim, self.hidden_local), "cls": (self.vocab_local, c.dim)}
         if name in shapes:
             return shapes[name], (np.int8 if gs else np.float32)
         if name.endswith("_s"):

@@ -429,6 +429,34 @@ def test_swiglu_add_embedding_argmax():
         assert int(di.numpy()[0]) == kxo.argmax(lg)
 
 
+def test_split_classifier_candidates_pick_the_first_maximum():
+    # four "ranks" each reduce their slice to a {value, global index} candidate; the pick over the
+    # gathered candidates is the first maximum of the whole vector, ties across slices included
+    rng = np.random.default_rng(12)
+    L = kx.lib()
+    n, ranks = 128256, 4
+    per = n // ranks
+    for case in range(3):
+        lg = rng.standard_normal(n).astype(np.float32)
+        if case == 1:
+            lg[[per - 1, per, 3 * per + 7]] = 9.0      # tie across three slices: lowest index wins
+        if case == 2:
+            lg[:] = -np.inf                            # nothing finite anywhere: token 0
+        dl = kx.Buf.from_numpy(lg)
+        cands = kx.Buf.zeros((ranks, 2))
+        ws = kx.Buf.zeros(L.kx_step_workspace_bytes(), np.uint8)
+        for r in range(ranks):
+            kx.check(L.kx_argmax_candidate_f32(dl.at(r * per * 4), per, r * per, cands.at(r * 8), ws.ptr,
+                                               ws.nbytes, None))
+        tok, pos = kx.Buf.zeros(1, np.int32), kx.Buf.from_numpy(np.array([5], np.int32))
+        hist = kx.Buf.zeros(16, np.int32)
+        kx.check(L.kx_decode_step_end_candidates(cands.ptr, ranks, tok.ptr, pos.ptr, hist.ptr, 16, None))
+        kx.sync()
+        want = kxo.argmax(lg) if case != 2 else 0
+        assert int(tok.numpy()[0]) == want and int(pos.numpy()[0]) == 6 and int(hist.numpy()[6]) == want
+    assert L.kx_argmax_candidate_f32(dl.ptr, per, 1 << 24, cands.ptr, ws.ptr, ws.nbytes, None) == -2
+
+
 def test_streams_events_graph_replay():
     rng = np.random.default_rng(1)
     K, M = 256, 1024

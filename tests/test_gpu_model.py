@@ -658,6 +658,15 @@ def test_tensor_parallel_ranks_equal_single_rank(tp, shape):
     for r in range(tp):
         np.testing.assert_array_equal(got[r], got[0])   # every rank ends with the same logits
     assert np.abs(got[0] - want).max() <= 1e-4 * np.abs(want).max()
+    # the classifier's rows are split over the ranks when the vocabulary divides by tp
+    assert ranks[0].read_weight("cls").shape[0] == (700 // tp if 700 % tp == 0 else 700)
+    # the reference-structured loop (op::MatmulLayer with its reducer, registry kernels) under the
+    # same sharding: row-parallel layers reduce through the model, the classifier slices are gathered
+    ref_layers = np.stack([one.forward_layers(int(t), p) for p, t in enumerate(toks[:3])])
+    got_layers = _run_ranks(ranks, lambda r, m: np.stack([m.forward_layers(int(t), p)
+                                                          for p, t in enumerate(toks[:3])]))
+    for r in range(tp):
+        assert np.abs(got_layers[r] - ref_layers).max() <= 1e-4 * np.abs(ref_layers).max()
     # each rank's cache rows are its kv heads' columns of the unsharded cache
     kvl = ranks[0].kv_dim_local
     for layer in range(shape["layer_num"]):
