@@ -74,6 +74,17 @@ __device__ __forceinline__ void st_device(float* p, float v) {
 __device__ __forceinline__ float ld_device(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 16- and 8-byte device-scope loads (buffer_load ... sc1; cache-policy bit 4 of the builtin)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 ld_device4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+  return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ float2 ld_device2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16);
+  return float2{__uint_as_float(v.x), __uint_as_float(v.y)};
+}
 
 template <int HS>
 struct AttnTile {
@@ -427,24 +438,39 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   if (nsplit == 1) return;
 
   // ---- the workgroup that arrives last for this kv head combines the splits ----
-  // Every storing wave drains its write-through stores before the workgroup takes a ticket; the
-  // barrier orders them (workgroup scope) before thread 0's release fence, which publishes them
-  // at device scope ahead of the ticket.  The stores are write-through already, so the fence's
-  // cache write-back finds nothing of this kernel's to do; it is what makes the hand-off a
-  // release/acquire pair in the memory model instead of a property of how the stores are emitted.
+  // The partial is published by three things together.  (1) Every element of it is stored with a
+  // device-scope atomic store, which the hardware writes through the XCD's L2, so no dirty line of
+  // this kernel ever needs a cache write-back.  (2) Each storing wave waits for the
+  // acknowledgement of its stores (vmcnt(0)); the asm's memory clobber keeps the compiler from
+  // moving a store below it.  (3) The barrier (a workgroup-scope release/acquire) orders all of
+  // that before thread 0's ticket.  A device-scope release fence in front of the ticket would
+  // say the same in the memory model's own terms, but it is emitted as an L2 write-back
+  // (buffer_wbl2) that every workgroup of the launch then pays for with nothing to write:
+  // measured +0.3 us per launch at 256 keys, +0.9 us at 1024, +3.0 us at 4096 keys with 64
+  // splits.  KX_ATTN_AGENT_RELEASE compiles it in for a build that wants it regardless.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stamp(3);  // partial stored and acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
+#ifdef KX_ATTN_AGENT_RELEASE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
     const unsigned old = atomicInc(&tickets[kvh * (kTicketStride / sizeof(unsigned))], (unsigned)nsplit - 1u);  // wraps back to 0
     sm_last = old == (unsigned)nsplit - 1u;
   }
   __syncthreads();
   stamp(4);  // ticket drawn
   if (!sm_last) return;
-  // Acquire at device scope, then ordinary 128-bit loads of the other workgroups' partials.
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // Every byte another workgroup wrote is read below with a device-scope (sc1) load, which goes
+  // past this CU's vector cache to where the write-through stores landed; nothing else of theirs
+  // is read.  That takes the place of a device-scope acquire fence, whose cache invalidate costs
+  // the merging workgroup about a microsecond before its first load; the wavefront-scope fence
+  // emits no instruction and only keeps the compiler from hoisting the loads above the ticket.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const __amdgpu_buffer_rsrc_t ws_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(ws, 0, 0x7fffffff, 0x00020000);
   // out[h][d] = sum_s O_s[d] e^{m_s-M} / sum_s l_s e^{m_s-M}.  One wave per head, no workgroup
   // barriers: a row of HS floats is HS/4 lanes wide, the wave's RG row groups take the splits
   // round-robin, and every load of a pass is in flight before the first is used.
@@ -455,7 +481,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   const int c4 = (lane % LPR) * 4, rg = lane / LPR;
   float* sf = sm_sf + wave * kMaxSplits;  // this wave's split weights
   for (int head = wave; head < kv_mul; head += kAttnWaves) {
-    const float* base = ws + (size_t)(kvh * kv_mul + head) * gridDim.y * stride;
+    // byte offset of this head's partials in the workspace (a few MiB at most)
+    const unsigned base = (unsigned)((kvh * kv_mul + head) * gridDim.y * stride) * 4u;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < nsplit; s0 += PASS * RG) {
       f32x4 ov[PASS];
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       for (int k = 0; k < PASS; ++k) {
         // rows past the last split re-read the last one; their weight below is zero
         const unsigned sp = min(s0 + k * RG + rg, nsplit - 1);
-        ov[k] = *reinterpret_cast<const f32x4*>(base + sp * (unsigned)stride + c4);
+        ov[k] = ld_device4(ws_rsrc, base + (sp * (unsigned)stride + c4) * 4u);
       }
       if (s0 == 0) {
         // split weights, one split per lane (two rounds cover kMaxSplits = 128)
@@ -475,7 +502,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
           // waited for on its own, one memory round trip per round
           const int sp = c * 64 + lane;
           const float2 ml =
-              *reinterpret_cast<const float2*>(base + (size_t)min(sp, nsplit - 1) * stride + HS);
+              ld_device2(ws_rsrc, base + ((unsigned)min(sp, nsplit - 1) * (unsigned)stride + HS) * 4u);
           m[c] = sp < nsplit ? ml.x : -INFINITY;
           l[c] = sp < nsplit ? ml.y : 0.f;
           M = fmaxf(M, m[c]);

@@ -48,3 +48,29 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(kx, "LIB_PATH", "/nonexistent/libkx_hip.so")
     with pytest.raises(kx.KxError):
         kx.lib()
+
+
+def test_split_attention_handoff_cache_policy(tmp_path):
+    """The in-launch hand-off of split partials has no fence to fall back on: it is correct only
+    while every partial store is a write-through (sc1) store and every merge load an sc1 load.
+    Compiles the kernel file to assembly and checks exactly that (hipcc cross-compiles on a CPU)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    pkg = os.path.join(ROOT, "llm-inference-engine_amd")
+    asm = tmp_path / "attn_decode.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(pkg, "csrc"), "-S", "--cuda-device-only",
+                    os.path.join(pkg, "csrc", "attn_decode.hip"), "-o", str(asm)], check=True,
+                   stderr=subprocess.DEVNULL)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_attn_asm
+    rows = check_attn_asm.audit(asm.read_text())
+    assert len(rows) >= 8
+    for r in rows:
+        assert r["stores_sc1"] >= 3, r
+        assert r["merge_loads"] > 0 and r["merge_loads"] == r["merge_loads_sc1"], r
+        assert r["buffer_inv"] == 0 and r["buffer_wbl2"] == 0, r
