@@ -330,25 +330,42 @@ int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index, void* stre
 
 /* End of one decode step, on the device (post_processing, llama3.cpp:801-813, without the
  * host round trip): token = argmax(logits); history[pos+1] = token (when history != NULL and in
- * range); pos += 1.  Two launches (slice-wise argmax, then the reduction and bookkeeping);
- * `workspace` of kx_step_workspace_bytes() carries the partial results. */
+ * range); pos += 1.  One launch: every workgroup reduces a slice to a {value, index} pair, and
+ * the workgroup that arrives last reduces the pairs and does the bookkeeping.  `workspace` of
+ * kx_step_workspace_bytes() carries the pairs and the arrival counter: it must be ZERO before its
+ * first use and is left ready for the next call by every call (calls that share a workspace
+ * must not overlap). */
 size_t kx_step_workspace_bytes(void);
 int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev, int32_t* pos_dev,
                        int32_t* history_dev, int32_t history_len, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same, and the embedding of the NEXT step in the same launch (the reference gathers it at the
+ * start of the next forward, llama3.cpp:622-640): with write_history != 0 the picked token is
+ * stored at history[pos+1]; otherwise (a prompt row) history keeps the token the caller put
+ * there.  Either way x_out = table[history[pos+1]] (dim floats) when `table` is given and pos+1
+ * is inside the history. */
+int kx_decode_step_end_embed(const float* logits, int32_t n, int32_t* token_dev, int32_t* pos_dev,
+                             int32_t* history_dev, int32_t history_len, int32_t write_history,
+                             const float* table, int32_t dim, int32_t vocab_size, float* x_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same step end for a classifier whose rows are split over tensor-parallel ranks (no
  * reference counterpart: the reference never shards, nccl_handler.cpp:60-80).  Each rank turns its
  * slice of the logits (`n` values, global index of the first = index_base) into one candidate
  * {value, global index as fp32}; the caller all-gathers the candidates ([ranks][2] floats) and
  * kx_decode_step_end_candidates picks the winner (largest value, lowest index on ties -- the first
- * maximum of the unsharded logits) and does the bookkeeping of kx_decode_step_end.  Indices must
- * stay below 2^24.  `workspace`: kx_step_workspace_bytes(). */
+ * maximum of the unsharded logits) and does the bookkeeping of kx_decode_step_end (the _embed
+ * form: that of kx_decode_step_end_embed).  Indices must stay below 2^24.  `workspace`:
+ * kx_step_workspace_bytes(), zero before its first use. */
 int kx_argmax_candidate_f32(const float* logits, int32_t n, int32_t index_base, float* candidate,
                             void* workspace, size_t workspace_bytes, void* stream);
 int kx_decode_step_end_candidates(const float* candidates, int32_t ranks, int32_t* token_dev,
                                   int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
                                   void* stream);
+int kx_decode_step_end_candidates_embed(const float* candidates, int32_t ranks, int32_t* token_dev,
+                                        int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
+                                        int32_t write_history, const float* table, int32_t dim,
+                                        int32_t vocab_size, float* x_out, void* stream);
 
 /* Seeded synthetic tensors generated on the device (the benchmarks run on random-init weights;
  * the reference reads real checkpoints through mmap, model.cpp:93-115).  dst is a dense

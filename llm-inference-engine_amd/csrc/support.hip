@@ -274,83 +274,110 @@ __device__ __forceinline__ void block_argmax(float& best, int& bi, float* sv, in
     for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
 }
 
-__global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ x, int n,
-                                                             float* __restrict__ pv,
-                                                             int32_t* __restrict__ pi) {
+// One launch for both stages.  Every workgroup publishes its pair with write-through stores and
+// draws an arrival ticket (the counter wraps back to zero on the last arrival, so a workspace
+// that was zero before its first use stays usable from launch to launch); the workgroup that
+// draws the last ticket reads all pairs with device-scope loads and finishes the step.  With a
+// table it also leaves the embedding row of the token at the NEW position (the one just picked,
+// or, when the history is not written, the prompt token already stored there) in x_out, which
+// is the input of the next step.
+struct StepArgs {
+  const float* logits; int n;
+  float* pv; int32_t* pi; unsigned* ticket;
+  int index_base; float* cand;                    // candidate form: {value, global index} and no bookkeeping
+  int32_t* token; int32_t* pos; int32_t* history; int history_len; int write_history;
+  const float* table; int dim; int vocab; float* x_out;
+};
+
+__device__ __forceinline__ void step_bookkeeping(const StepArgs& a, int bi, int* sm_tok) {
+  // thread 0 only
+  if (bi == 0x7fffffff) bi = 0;
+  const int p = *a.pos;
+  if (a.history && a.write_history && p + 1 < a.history_len) a.history[p + 1] = bi;
+  *a.token = bi;
+  *a.pos = p + 1;
+  int nxt = -1;
+  if (a.table && a.x_out && a.history && p + 1 < a.history_len) nxt = a.write_history ? bi : a.history[p + 1];
+  *sm_tok = nxt;
+}
+
+__device__ __forceinline__ void step_embed(const StepArgs& a, int tok) {
+  // whole workgroup; tok < 0: nothing to do
+  if (tok < 0) return;
+  if (tok >= a.vocab) tok = 0;
+  const float* src = a.table + (size_t)tok * a.dim;
+  if (a.dim % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)a.x_out % 16 == 0)) {
+    for (int i = threadIdx.x; i < a.dim / 4; i += blockDim.x)
+      reinterpret_cast<f32x4*>(a.x_out)[i] = reinterpret_cast<const f32x4*>(src)[i];
+  } else {
+    for (int i = threadIdx.x; i < a.dim; i += blockDim.x) a.x_out[i] = src[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void step_pick_kernel(const StepArgs a) {
   __shared__ float sv[4];
   __shared__ int si[4];
-  const int per = (n + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per, hi = min(lo + per, n);
+  __shared__ int sm_last, sm_tok;
+  const int per = (a.n + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(lo + per, a.n);
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float v = x[i];
-    if (v > best) {
+    const float v = a.logits[i];
+    if (v > best) {  // strictly greater: the lowest index of a thread's stripe wins ties
       best = v;
       bi = i;
     }
   }
   block_argmax(best, bi, sv, si);
-  if (threadIdx.x == 0) {
-    pv[blockIdx.x] = best;
-    pi[blockIdx.x] = bi;
+  if (gridDim.x > 1) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(a.pv + blockIdx.x, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.pi + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both stores acknowledged before the ticket
+      sm_last = atomicInc(a.ticket, gridDim.x - 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: the loads below are device-scope
+    best = -INFINITY;
+    bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+      argmax_merge(best, bi, __hip_atomic_load(a.pv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(a.pi + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();  // sv / si are reused
+    block_argmax(best, bi, sv, si);
   }
-}
-
-__global__ __launch_bounds__(256) void decode_step_end_kernel(const float* __restrict__ pv,
-                                                              const int32_t* __restrict__ pi,
-                                                              int nparts, int32_t* token,
-                                                              int32_t* pos, int32_t* history,
-                                                              int history_len) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) argmax_merge(best, bi, pv[i], pi[i]);
-  block_argmax(best, bi, sv, si);
-  if (threadIdx.x == 0) {
-    if (bi == 0x7fffffff) bi = 0;
-    const int p = *pos;
-    if (history && p + 1 < history_len) history[p + 1] = bi;
-    *token = bi;
-    *pos = p + 1;
+  if (a.cand) {
+    if (threadIdx.x == 0) {
+      a.cand[0] = best;
+      a.cand[1] = bi == 0x7fffffff ? -1.0f : (float)(a.index_base + bi);
+    }
+    return;
   }
+  if (threadIdx.x == 0) step_bookkeeping(a, bi, &sm_tok);
+  __syncthreads();
+  step_embed(a, sm_tok);
 }
 
 // Tensor-parallel greedy pick over a row-split classifier: every rank reduces ITS slice of the
-// logits to one candidate {value, global index (exact in fp32: < 2^24)}, the candidates are
-// all-gathered, and every rank picks the same winner (largest value, lowest index on ties: the
-// first maximum of the unsharded vector, argmax_sampler.cpp:6-8).
-__global__ __launch_bounds__(256) void argmax_candidate_kernel(const float* __restrict__ pv,
-                                                               const int32_t* __restrict__ pi,
-                                                               int nparts, int index_base,
-                                                               float* __restrict__ cand) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) argmax_merge(best, bi, pv[i], pi[i]);
-  block_argmax(best, bi, sv, si);
+// logits to one candidate {value, global index (exact in fp32: < 2^24)} (step_pick_kernel with
+// `cand`), the candidates are all-gathered, and every rank picks the same winner (largest value,
+// lowest index on ties: the first maximum of the unsharded vector, argmax_sampler.cpp:6-8).
+__global__ __launch_bounds__(256) void step_end_candidates_kernel(const float* __restrict__ cands,
+                                                                  int ranks, const StepArgs a) {
+  __shared__ int sm_tok;
   if (threadIdx.x == 0) {
-    cand[0] = best;
-    cand[1] = bi == 0x7fffffff ? -1.0f : (float)(index_base + bi);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int r = 0; r < ranks; ++r) {
+      const float idx = cands[2 * r + 1];
+      if (idx >= 0.f) argmax_merge(best, bi, cands[2 * r], (int)idx);
+    }
+    step_bookkeeping(a, bi, &sm_tok);
   }
-}
-
-__global__ void step_end_candidates_kernel(const float* __restrict__ cands, int ranks, int32_t* token,
-                                           int32_t* pos, int32_t* history, int history_len) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int r = 0; r < ranks; ++r) {
-    const float idx = cands[2 * r + 1];
-    if (idx >= 0.f) argmax_merge(best, bi, cands[2 * r], (int)idx);
-  }
-  if (bi == 0x7fffffff) bi = 0;
-  const int p = *pos;
-  if (history && p + 1 < history_len) history[p + 1] = bi;
-  *token = bi;
-  *pos = p + 1;
+  __syncthreads();
+  step_embed(a, sm_tok);
 }
 
 // ---- seeded synthetic tensors, generated on the device ----
@@ -485,23 +512,41 @@ extern "C" int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index,
   return KX_OK;
 }
 
-extern "C" size_t kx_step_workspace_bytes(void) { return kStepBlocks * 8; }
+// pairs of the first stage, then the arrival ticket in a 256-byte block of its own
+constexpr size_t kStepTicketOff = kStepBlocks * 8;
+extern "C" size_t kx_step_workspace_bytes(void) { return kStepTicketOff + 256; }
+
+static int step_pick_launch(kx::StepArgs a, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!workspace || workspace_bytes < kx_step_workspace_bytes()) return KX_EWORKSPACE;
+  a.pv = static_cast<float*>(workspace);
+  a.pi = reinterpret_cast<int32_t*>(a.pv + kx::kStepBlocks);
+  a.ticket = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kStepTicketOff);
+  const int blocks = a.n < kx::kStepBlocks * 256 ? (a.n + 255) / 256 : kx::kStepBlocks;
+  hipLaunchKernelGGL(kx::step_pick_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_decode_step_end_embed(const float* logits, int32_t n, int32_t* token_dev,
+                                        int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
+                                        int32_t write_history, const float* table, int32_t dim,
+                                        int32_t vocab_size, float* x_out, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  if (!logits || !token_dev || !pos_dev || n <= 0) return KX_EINVAL;
+  if (table && (!x_out || !history_dev || dim <= 0 || vocab_size <= 0)) return KX_EINVAL;
+  kx::StepArgs a{};
+  a.logits = logits; a.n = n;
+  a.token = token_dev; a.pos = pos_dev; a.history = history_dev; a.history_len = history_len;
+  a.write_history = write_history != 0;
+  a.table = table; a.dim = dim; a.vocab = vocab_size; a.x_out = x_out;
+  return step_pick_launch(a, workspace, workspace_bytes, stream);
+}
 
 extern "C" int kx_decode_step_end(const float* logits, int32_t n, int32_t* token_dev,
                                   int32_t* pos_dev, int32_t* history_dev, int32_t history_len,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-  if (!logits || !token_dev || !pos_dev || n <= 0) return KX_EINVAL;
-  if (!workspace || workspace_bytes < kStepBlocks * 8) return KX_EWORKSPACE;
-  float* pv = reinterpret_cast<float*>(workspace);
-  int32_t* pi = reinterpret_cast<int32_t*>(pv + kStepBlocks);
-  const int blocks = n < kStepBlocks * 256 ? (n + 255) / 256 : kStepBlocks;
-  hipLaunchKernelGGL(argmax_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits,
-                     n, pv, pi);
-  KX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pv, pi,
-                     blocks, token_dev, pos_dev, history_dev, history_len);
-  KX_LAUNCH_CHECK();
-  return KX_OK;
+  return kx_decode_step_end_embed(logits, n, token_dev, pos_dev, history_dev, history_len, 1, nullptr, 0,
+                                  0, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int kx_argmax_candidate_f32(const float* logits, int32_t n, int32_t index_base,
@@ -509,14 +554,25 @@ extern "C" int kx_argmax_candidate_f32(const float* logits, int32_t n, int32_t i
                                        void* stream) {
   if (!logits || n <= 0 || index_base < 0 || !candidate) return KX_EINVAL;
   if ((int64_t)index_base + n > (1 << 24)) return KX_EUNSUPPORTED;  // indices travel as fp32
-  if (!workspace || workspace_bytes < kStepBlocks * 8) return KX_EWORKSPACE;
-  float* pv = static_cast<float*>(workspace);
-  int32_t* pi = reinterpret_cast<int32_t*>(pv + kStepBlocks);
-  const int blocks = n < kStepBlocks * 256 ? (n + 255) / 256 : kStepBlocks;
-  hipLaunchKernelGGL(argmax_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, n,
-                     pv, pi);
-  hipLaunchKernelGGL(argmax_candidate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pv, pi,
-                     blocks, index_base, candidate);
+  kx::StepArgs a{};
+  a.logits = logits; a.n = n; a.index_base = index_base; a.cand = candidate;
+  return step_pick_launch(a, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kx_decode_step_end_candidates_embed(const float* candidates, int32_t ranks,
+                                                   int32_t* token_dev, int32_t* pos_dev,
+                                                   int32_t* history_dev, int32_t history_len,
+                                                   int32_t write_history, const float* table,
+                                                   int32_t dim, int32_t vocab_size, float* x_out,
+                                                   void* stream) {
+  if (!candidates || ranks <= 0 || !token_dev || !pos_dev) return KX_EINVAL;
+  if (table && (!x_out || !history_dev || dim <= 0 || vocab_size <= 0)) return KX_EINVAL;
+  kx::StepArgs a{};
+  a.token = token_dev; a.pos = pos_dev; a.history = history_dev; a.history_len = history_len;
+  a.write_history = write_history != 0;
+  a.table = table; a.dim = dim; a.vocab = vocab_size; a.x_out = x_out;
+  hipLaunchKernelGGL(kx::step_end_candidates_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                     candidates, ranks, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -524,11 +580,8 @@ extern "C" int kx_argmax_candidate_f32(const float* logits, int32_t n, int32_t i
 extern "C" int kx_decode_step_end_candidates(const float* candidates, int32_t ranks,
                                              int32_t* token_dev, int32_t* pos_dev,
                                              int32_t* history_dev, int32_t history_len, void* stream) {
-  if (!candidates || ranks <= 0 || !token_dev || !pos_dev) return KX_EINVAL;
-  hipLaunchKernelGGL(step_end_candidates_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, candidates,
-                     ranks, token_dev, pos_dev, history_dev, history_len);
-  KX_LAUNCH_CHECK();
-  return KX_OK;
+  return kx_decode_step_end_candidates_embed(candidates, ranks, token_dev, pos_dev, history_dev,
+                                             history_len, 1, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int kx_fill_hash_i8(int8_t* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0,

@@ -215,6 +215,7 @@ class LlamaModel {
 
   // profiling (profile_gemv)
   bool prof_on_ = false;
+  bool x_valid_ = false;  // x_ holds the embedding of history[pos] (left by the previous step's end)
   int64_t prof_launches_ = 0;
   double prof_bytes_sum_ = 0;
 };

@@ -181,6 +181,7 @@ base::Status LlamaModel::init(const TransformerConfig& cfg_in) {
   ST_RET(dev_alloc(pos_dev_, 1));
   ST_RET(dev_alloc(history_dev_, cfg_.seq_len + 1));
   ST_RET(dev_alloc(step_ws_, kx_step_workspace_bytes() / sizeof(float)));
+  KX_RET(kx_memset(step_ws_, 0, kx_step_workspace_bytes(), hip_->stream));  // the arrival counter starts at zero
   KX_RET(kx_sin_cos_cache_f32(cfg_.head_size, cfg_.seq_len, cfg_.rope_theta, sin_, cos_,
                               hip_->stream));
 
@@ -666,6 +667,7 @@ base::Status LlamaModel::forward_layers(int32_t token, int32_t pos, float* logit
   R.pos_tensor.index<int32_t>(0) = pos;
   R.token_tensor.index<int32_t>(0) = token;
   tensor::Tensor x = view(base::DataType::kDataTypeFp32, {c.dim}, x_);
+  x_valid_ = false;  // this loop uses x_ for its own token
   // embedding (llama3.cpp:615-635)
   ST_RET(R.embedding->forward(R.token_tensor, R.token_num, buf[B::kInputEmbeddings]));
   for (int32_t l = 0; l < c.layer_num; ++l) {
@@ -776,7 +778,11 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
   const TransformerConfig& c = cfg_;
   if (!quant_) return base::error::FunctionNotImplement("the fused path needs int8 weights");
   const bool all = !prof_on_;  // profiling keeps only the GEMV launches
-  if (all) KX_RET(kx_embedding_dpos_f32(history_dev_, pos_dev_, emb_, c.dim, c.vocab_size, x_, st));
+  // x_ holds the embedding of history[pos]: left there by the previous step's last launch, or
+  // gathered here after the host changed the state (never inside a captured step: decode()
+  // makes it valid before it captures or replays)
+  if (all && !x_valid_) KX_RET(kx_embedding_dpos_f32(history_dev_, pos_dev_, emb_, c.dim, c.vocab_size, x_, st));
+  x_valid_ = false;  // the layers overwrite it; classify_and_pick() makes it valid again
   const int32_t ql = c.q_dim_local, kl = c.kv_dim_local;
   for (int32_t l = 0; l < c.layer_num; ++l) {
     const LayerWeights& lw = layers_[l];
@@ -811,12 +817,16 @@ base::Status LlamaModel::classify_and_pick(const float* x_row, bool write_histor
   const TransformerConfig& c = cfg_;
   float* local = logits_ + c.vocab_row0;
   ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_row, final_norm_, local, nullptr, nullptr, 0, 0, nullptr, st));
-  int32_t* hist = write_history ? history_dev_ : nullptr;
+  // the step's last launch also gathers the next step's input row: emb[history[pos + 1]]
+  const bool embed = quant_ && !prof_on_;
+  const float* table = embed ? emb_ : nullptr;
   // a communicator of one rank takes the candidate route too, so that route (its extra launches
   // and its collective) can be exercised, graph capture included, on a single GPU
   if (!c.cls_split && !(comm_ready_ && c.tp_size == 1)) {
-    KX_RET(kx_decode_step_end(local, c.vocab_local, token_dev_, pos_dev_, hist, c.seq_len + 1, step_ws_,
-                              kx_step_workspace_bytes(), st));
+    KX_RET(kx_decode_step_end_embed(local, c.vocab_local, token_dev_, pos_dev_, history_dev_, c.seq_len + 1,
+                                    write_history, table, c.dim, c.vocab_size, x_, step_ws_,
+                                    kx_step_workspace_bytes(), st));
+    x_valid_ = embed;
     return base::error::Success();
   }
   // this rank's best {value, global index} into slot (1 + rank); all-gather the slots; same pick everywhere
@@ -824,7 +834,9 @@ base::Status LlamaModel::classify_and_pick(const float* x_row, bool write_histor
   KX_RET(kx_argmax_candidate_f32(local, c.vocab_local, c.vocab_row0, slots + 2 * c.tp_rank, step_ws_,
                                  kx_step_workspace_bytes(), st));
   ST_RET(all_gather(slots, 2));
-  KX_RET(kx_decode_step_end_candidates(slots, c.tp_size, token_dev_, pos_dev_, hist, c.seq_len + 1, st));
+  KX_RET(kx_decode_step_end_candidates_embed(slots, c.tp_size, token_dev_, pos_dev_, history_dev_,
+                                             c.seq_len + 1, write_history, table, c.dim, c.vocab_size, x_, st));
+  x_valid_ = embed;
   return base::error::Success();
 }
 
@@ -853,6 +865,7 @@ base::Status LlamaModel::set_state(int32_t token, int32_t pos) {
   KX_RET(kx_memcpy_h2d(token_dev_, &token, 4, nullptr));
   KX_RET(kx_memcpy_h2d(pos_dev_, &pos, 4, nullptr));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos, &token, 4, nullptr));
+  x_valid_ = false;
   return base::error::Success();
 }
 
@@ -875,6 +888,11 @@ base::Status LlamaModel::decode(int32_t steps, bool use_graph) {
   void* st = hip_->stream;
   if (use_graph && loop_)
     return base::error::InvalidArgument("the loopback communicator cannot be captured into a graph");
+  // the captured step has no embedding launch: its input row is left by the step before it
+  if (use_graph && !x_valid_ && quant_) {
+    KX_RET(kx_embedding_dpos_f32(history_dev_, pos_dev_, emb_, cfg_.dim, cfg_.vocab_size, x_, st));
+    x_valid_ = true;
+  }
   if (use_graph) {
     if (!graph_) {
       // one eager step first: lazy per-kernel setup (e.g. raising a kernel's LDS limit) must
@@ -903,6 +921,7 @@ base::Status LlamaModel::prefill_sequential(const int32_t* tokens, int32_t n, in
   KX_RET(kx_stream_sync(hip_->stream));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
   KX_RET(kx_memcpy_h2d(pos_dev_, &pos0, 4, nullptr));
+  x_valid_ = false;
   for (int32_t i = 0; i < n; ++i) ST_RET(launch_step(hip_->stream, false));
   ST_RET(gather_logits());
   KX_RET(kx_stream_sync(hip_->stream));
@@ -910,6 +929,7 @@ base::Status LlamaModel::prefill_sequential(const int32_t* tokens, int32_t n, in
   int32_t next = 0;
   KX_RET(kx_memcpy_d2h(&next, token_dev_, 4, nullptr));
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0 + n, &next, 4, nullptr));
+  x_valid_ = false;  // the last row's step end ran before history[pos0 + n] was known
   if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)cfg_.vocab_size * 4, nullptr));
   return base::error::Success();
 }
@@ -1204,6 +1224,7 @@ base::Status LlamaModel::profile_gemv(int32_t steps, int64_t* launches, double* 
     if (s && rc) s = base::error::InternalError("graph capture failed");
   }
   prof_on_ = false;
+  x_valid_ = false;  // the profiled launches ran on the model's own buffers
   ST_RET(s);
   void *e0 = nullptr, *e1 = nullptr;
   KX_RET(kx_event_create(&e0));

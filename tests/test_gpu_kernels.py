@@ -457,6 +457,57 @@ def test_split_classifier_candidates_pick_the_first_maximum():
     assert L.kx_argmax_candidate_f32(dl.ptr, per, 1 << 24, cands.ptr, ws.ptr, ws.nbytes, None) == -2
 
 
+def test_step_end_in_one_launch_with_the_next_embedding():
+    # greedy pick + bookkeeping + the next step's embedding row, one launch, the same workspace
+    # reused call after call (its arrival counter must come back to zero every time)
+    rng = np.random.default_rng(21)
+    L = kx.lib()
+    dim, vocab = 2048, 128256
+    table = rng.standard_normal((vocab, 8)).astype(np.float32)  # narrow table, wide enough to tell rows apart
+    table = np.ascontiguousarray(np.tile(table, (1, dim // 8)))
+    dt = kx.Buf.from_numpy(table)
+    ws = kx.Buf.zeros(L.kx_step_workspace_bytes(), np.uint8)
+    hist_len = 32
+    for case, n in enumerate((vocab, vocab, 1000, 200, vocab)):
+        lg = rng.standard_normal(n).astype(np.float32)
+        if case == 1:
+            lg[[300, 70000, 128000]] = 11.0          # a tie across workgroups: the lowest index wins
+        if case == 4:
+            lg[:] = -np.inf                          # nothing finite: token 0
+        want = kxo.argmax(lg) if case != 4 else 0
+        dl = kx.Buf.from_numpy(lg)
+        tok, pos = kx.Buf.zeros(1, np.int32), kx.Buf.from_numpy(np.array([7 + case], np.int32))
+        h0 = rng.integers(0, n, hist_len).astype(np.int32)
+        hist = kx.Buf.from_numpy(h0)
+        x = kx.Buf.zeros(dim)
+        write = 0 if case == 2 else 1                # case 2: a prompt row, the history keeps its token
+        kx.check(L.kx_decode_step_end_embed(dl.ptr, n, tok.ptr, pos.ptr, hist.ptr, hist_len, write, dt.ptr, dim,
+                                            vocab, x.ptr, ws.ptr, ws.nbytes, None))
+        kx.sync()
+        p1 = 8 + case
+        assert int(tok.numpy()[0]) == want and int(pos.numpy()[0]) == p1
+        h = hist.numpy()
+        nxt = want if write else int(h0[p1])
+        assert int(h[p1]) == nxt and np.array_equal(np.delete(h, p1), np.delete(h0, p1))
+        assert np.array_equal(x.numpy(), table[nxt])
+        assert not ws.numpy(np.uint8, (ws.nbytes,))[-256:].any()      # counter back at zero
+        # the plain form: same pick, no embedding, NULL history allowed
+        tok2, pos2 = kx.Buf.zeros(1, np.int32), kx.Buf.from_numpy(np.array([3], np.int32))
+        kx.check(L.kx_decode_step_end(dl.ptr, n, tok2.ptr, pos2.ptr, None, 0, ws.ptr, ws.nbytes, None))
+        kx.sync()
+        assert int(tok2.numpy()[0]) == want and int(pos2.numpy()[0]) == 4
+    # past the end of the history nothing is gathered or stored
+    pos = kx.Buf.from_numpy(np.array([hist_len - 1], np.int32))
+    x = kx.Buf.zeros(dim)
+    kx.check(L.kx_decode_step_end_embed(dl.ptr, n, tok.ptr, pos.ptr, hist.ptr, hist_len, 1, dt.ptr, dim, vocab,
+                                        x.ptr, ws.ptr, ws.nbytes, None))
+    kx.sync()
+    assert int(pos.numpy()[0]) == hist_len and not x.numpy().any() and np.array_equal(hist.numpy(), h)
+    assert L.kx_decode_step_end_embed(dl.ptr, n, tok.ptr, pos.ptr, None, 0, 1, dt.ptr, dim, vocab, x.ptr,
+                                      ws.ptr, ws.nbytes, None) == -1
+    assert L.kx_decode_step_end(dl.ptr, n, tok.ptr, pos.ptr, None, 0, ws.ptr, 64, None) == -3
+
+
 def test_streams_events_graph_replay():
     rng = np.random.default_rng(1)
     K, M = 256, 1024
