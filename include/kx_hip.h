@@ -181,6 +181,19 @@ int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales, 
                          float* y2, int64_t ld2, int32_t k0, int32_t k1, const float* residual,
                          int64_t ldr, int32_t T, int32_t M, int32_t K, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same with a second workspace (kx_gemm_split_workspace_bytes(); no reference counterpart)
+ * through which the 256 x 256-tile kernel balances a last, partial round of tiles: the reduction
+ * of each of those tiles is cut into 2 or 4 parts that run on otherwise idle CUs, the parts meet in
+ * fp32 slabs and the workgroup that finishes last adds them in index order (results do not depend
+ * on arrival order).  The first 4096 bytes (arrival tickets) must be ZERO before the first use and
+ * are left zero by every call; calls that share it must not overlap.  NULL: never cut. */
+size_t kx_gemm_split_workspace_bytes(void);
+int kx_gemm_w8_f16act_split_ws(const void* X16, const int8_t* w, const float* scales,
+                               int32_t group_size, int32_t mode, void* h16, float* y0, int64_t ld0,
+                               float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
+                               const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
+                               void* workspace, size_t workspace_bytes, void* split_workspace,
+                               size_t split_workspace_bytes, void* stream);
 int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, int32_t K,
                 void* stream);
 

@@ -34,6 +34,12 @@ struct GemmF16Args {
   int64_t ld0, ld1, ld2, ldr;
   int32_t k0, k1;
   int32_t T, M, K;
+  // pipelined kernel only: tiles [full_tiles, tiles) have their reduction cut into `split` parts,
+  // one workgroup each, combined through fp32 slabs and one arrival ticket per tile
+  float* slabs;
+  unsigned* tickets;
+  int32_t full_tiles, split;
+  int32_t wide_rows;  // every destination row is 16-byte aligned: the epilogue may use 16-byte accesses
 };
 
 // X fp32 [T][ldx] -> fp16 [T][ldy], M columns
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16_swiglu_kernel_22(const GemmF1
 constexpr int GP_BUF = 65536, GP_BOFF = 32768;
 constexpr int GP_GROUP_N = 4;
 using gp_lds_ptr_t = __attribute__((address_space(3))) void*;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmPipeCtx {
   const _Float16* src[4][2];  // per piece: this lane's source of its two fill instructions
@@ -410,6 +417,126 @@ __device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t,
   GP_PHASE(1, PAR, t + 2, 4, 0, bq0);
 }
 
+// Epilogue of the pipelined kernel through LDS (free once the main loop is over): a wave turns
+// its 128 x 64 accumulator tile, 64 rows at a time, from "lane = column, 4 rows per register
+// quad" into "16 lanes = one row of 64 columns", so that results leave as 16-byte stores in
+// 256-byte row segments (and the residual arrives the same way) instead of 128 dword stores per
+// lane in 64-byte pieces -- measured on 4096 rows: the dword form took 135 of the 317 us of the
+// Wq|Wk|Wv product and 57 of the 162 us of Wo.  Each wave uses its own 16 KiB of LDS, so no
+// workgroup barrier is needed between its writes and reads.  The 16-column blocks of a row are
+// stored XOR-ed with the row's quad index, which spreads a write instruction over all banks.
+// Needs 16-byte aligned rows in every destination; the caller falls back to the dword form.
+template <bool SWIGLU>
+__device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, const f32x4 (&acc)[8][4],
+                                                       char* smem, int trow0, int ncol0, int wave, int lane) {
+  const int c16 = lane & 15, g = lane >> 4;
+  if constexpr (SWIGLU) {
+    // blocks 0,1 = gate, 2,3 = up of 32 hidden units; the workgroup's 256 rows x 128 units go to
+    // LDS as fp16 (64 KiB; 16-byte chunk c of row r kept at chunk c ^ (r & 15)) and leave as
+    // 256-byte row segments
+    _Float16* wb = reinterpret_cast<_Float16*>(smem);
+    const int half_k = a.K / 2;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tile_row0 = trow0 - wr * 128, tile_j0 = ((ncol0 - wc * 64) >> 6) * 32;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = ncol0 + ni * 16 + c16;
+      const float fg = n < a.K ? a.colf[n] : 0.f, fu = n < a.K ? a.colf[n + 32] : 0.f;
+      const int unit = wc * 32 + ni * 16 + c16;
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 128 + mi * 16 + 4 * g + r;
+          const float gv = acc[mi][ni][r] * fg, uv = acc[mi][ni + 2][r] * fu;
+          wb[row * 128 + ((((unit >> 3) ^ (row & 15)) << 3) | (unit & 7))] =
+              (_Float16)(gv * (1.0f / (1.0f + expf(-gv))) * uv);
+        }
+    }
+    __syncthreads();
+    // 16 lanes = one row of 128 units, 4 rows per instruction, 32 rows per wave
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = wave * 32 + it * 4 + g, t = tile_row0 + row, j = tile_j0 + c16 * 8;
+      const f16x8 v = *reinterpret_cast<const f16x8*>(wb + row * 128 + ((c16 ^ (row & 15)) << 3));
+      if (t < a.T && j < half_k) *reinterpret_cast<f16x8*>(a.h16 + (size_t)t * half_k + j) = v;
+    }
+    return;
+  } else {
+    float* wb = reinterpret_cast<float*>(smem) + wave * 4096;
+    float f[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = ncol0 + ni * 16 + c16;
+      f[ni] = n < a.K ? a.colf[n] : 0.f;
+    }
+    // this lane's four columns when reading back, and where they go
+    const int n4 = ncol0 + 4 * c16;
+    float* dst;
+    int64_t ld;
+    int col;
+    bool add_res = false;
+    if (n4 < a.k0) {
+      dst = a.y0; ld = a.ld0; col = n4; add_res = a.residual != nullptr;
+    } else if (n4 < a.k1) {
+      dst = a.y1; ld = a.ld1; col = n4 - a.k0;
+    } else {
+      dst = a.y2; ld = a.ld2; col = n4 - a.k1;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            wb[(m4 * 16 + 4 * g + r) * 64 + ((ni * 16 + c16) ^ (16 * g))] = acc[half * 4 + m4][ni][r] * f[ni];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + g, t = trow0 + half * 64 + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(wb + row * 64 + ((4 * c16) ^ (16 * ((row >> 2) & 3))));
+        if (t < a.T && n4 < a.K) {
+          if (add_res) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + (size_t)t * a.ldr + col);
+            v += rv;
+          }
+          *reinterpret_cast<f32x4*>(dst + (size_t)t * ld + col) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites
+    }
+  }
+}
+
+// acc = part 0 + part 1 + ... in index order, every part (this workgroup's own too) read back from
+// its slab with device-scope loads; the loads of one row of blocks are all in flight together.
+template <int S>
+__device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t rs, unsigned lane_off) {
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    u32x4 v[S][4];
+#pragma unroll
+    for (int pp = 0; pp < S; ++pp)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        v[pp][ni] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (unsigned)pp * 262144u + lane_off + (mi * 4 + ni) * 1024, 0, 16);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      f32x4 t = {__uint_as_float(v[0][ni].x), __uint_as_float(v[0][ni].y), __uint_as_float(v[0][ni].z),
+                 __uint_as_float(v[0][ni].w)};
+#pragma unroll
+      for (int pp = 1; pp < S; ++pp) {
+        t[0] += __uint_as_float(v[pp][ni].x); t[1] += __uint_as_float(v[pp][ni].y);
+        t[2] += __uint_as_float(v[pp][ni].z); t[3] += __uint_as_float(v[pp][ni].w);
+      }
+      acc[mi][ni] = t;
+    }
+  }
+}
+
 template <bool SWIGLU>
 __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -419,8 +546,16 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   // workgroups that share an XCD (ids equal mod 8) take consecutive tiles, walking down the token
   // dimension first: they share W column panels through that XCD's L2
   const int tiles_m = (a.T + 255) / 256;
-  const int nwg = gridDim.x, q8 = nwg >> 3, r8n = nwg & 7, xcd = blockIdx.x & 7;
-  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
+  // two classes of workgroups, whole tiles first: each class is dealt over the XCDs on its own,
+  // so every XCD gets the same share of both
+  const bool whole = (int)blockIdx.x < a.full_tiles;
+  const int bid = whole ? blockIdx.x : blockIdx.x - a.full_tiles;
+  const int nwg = whole ? a.full_tiles : (int)gridDim.x - a.full_tiles;
+  const int q8 = nwg >> 3, r8n = nwg & 7, xcd = bid & 7;
+  const int unit = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (bid >> 3);
+  const int nsplit = whole ? 1 : a.split;
+  const int wgid = whole ? unit : a.full_tiles + unit / nsplit;
+  const int part = whole ? 0 : unit % nsplit;
   // inside that sequence, panels of GP_GROUP_N column tiles are walked column-first: the ~32
   // workgroups an XCD runs at a time then cover about 8 x 4 tiles and share 12 operand panels
   // instead of 18
@@ -430,7 +565,13 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   const int t0 = (local / gn) * 256, n0 = (panel * GP_GROUP_N + local % gn) * 256;
 
   GemmPipeCtx c;
-  c.nt = a.M / GF_BK;
+  // this workgroup's share of the reduction: K-tiles [kt0, kt0 + c.nt)
+  int kt0 = 0;
+  {
+    const int nt_all = a.M / GF_BK, base = nt_all / nsplit, rem = nt_all % nsplit;
+    kt0 = part * base + min(part, rem);
+    c.nt = base + (part < rem ? 1 : 0);
+  }
   {
     const int r8 = lane >> 3;
 #pragma unroll
@@ -444,8 +585,8 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
         const int rl = row + r8;
         const int chunk = (lane & 7) ^ ((rl >> 1) & 7);
         // rows past the end re-read the last valid row; their outputs are never stored
-        c.src[piece][j] = is_a ? a.X + (size_t)min(t0 + rl, a.T - 1) * a.M + chunk * 8
-                               : a.W + (size_t)min(n0 + rl, a.K - 1) * a.M + chunk * 8;
+        c.src[piece][j] = (is_a ? a.X + (size_t)min(t0 + rl, a.T - 1) * a.M + chunk * 8
+                                : a.W + (size_t)min(n0 + rl, a.K - 1) * a.M + chunk * 8) + kt0 * GF_BK;
         c.dst[piece][j] = (is_a ? 0 : GP_BOFF) + row * 128;
       }
     }
@@ -488,15 +629,79 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads target this LDS
-  gemm_f16_epilogue16<8, 4, SWIGLU>(a, acc, t0 + wr * 128, n0 + wc * 64, lane);
+  if (nsplit > 1) {
+    // Partial sums of one tile meet in fp32 slabs ([part][wave][block][lane] x 16 bytes: whole
+    // 1 KiB lines per wave instruction).  Write-through stores, drained by every wave, then one
+    // arrival ticket per tile (it wraps back to zero); the workgroup that arrives last adds the
+    // parts in index order -- the same sum whichever arrives last -- with device-scope loads
+    // and writes the tile.  No workgroup ever waits for another.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.slabs + (size_t)(wgid - a.full_tiles) * nsplit * 65536, 0, (unsigned)nsplit * 262144u, 0x00020000);
+    const unsigned mine = (unsigned)part * 262144u + (unsigned)(wave * 32 * 1024 + lane * 16);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        u32x4 v;
+        v.x = __float_as_uint(acc[mi][ni][0]); v.y = __float_as_uint(acc[mi][ni][1]);
+        v.z = __float_as_uint(acc[mi][ni][2]); v.w = __float_as_uint(acc[mi][ni][3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + (mi * 4 + ni) * 1024, 0, 16);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // also: every wave is past its last read of the K-tile buffers
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = atomicInc(a.tickets + (wgid - a.full_tiles), (unsigned)nsplit - 1u) == (unsigned)nsplit - 1u;
+    __syncthreads();
+    const int last = *flag;
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: sc1 loads below
+    const unsigned lane_off = (unsigned)(wave * 32 * 1024 + lane * 16);
+    if (nsplit == 2) gp_combine<2>(acc, rs, lane_off);
+    else gp_combine<4>(acc, rs, lane_off);
+  }
+  if (a.wide_rows) {
+    __syncthreads();  // every wave's last tile reads and LDS-DMA landings are over: LDS is free
+    gemm_pipe_epilogue_lds<SWIGLU>(a, acc, smem, t0 + wr * 128, n0 + wc * 64, wave, lane);
+  } else {
+    gemm_f16_epilogue16<8, 4, SWIGLU>(a, acc, t0 + wr * 128, n0 + wc * 64, lane);
+  }
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true>(a); }
 
+// Split workspace: kSplitTicketBytes of arrival tickets (one per tile of the last, partial round),
+// then 256 KiB slabs.
+constexpr size_t kSplitTicketBytes = 4096;
+constexpr size_t kSplitSlabBytes = 256 * 256 * 4;
+constexpr int kPipeCUs = 256;
+
+// How many parts (1, 2 or 4) the reduction of the tiles of the last, partial round is cut into.
+// Model, in microseconds (fitted on 8B-sized matrices at 512..4096 rows): a K-tile step takes
+// ~1.45; a round of R tiles cut S ways costs ceil(R S / 256) rounds of nt / S steps, plus the
+// slabs' way through memory -- every part writes 256 KiB and the last arriver reads them all
+// back, ~0.16 per slab with the whole chip doing it at once.
+static int pipe_split_choice(int tiles, int nt, size_t split_ws_bytes) {
+  const int R = tiles % kPipeCUs;
+  if (R == 0 || split_ws_bytes <= kSplitTicketBytes) return 1;
+  const size_t slabs_fit = (split_ws_bytes - kSplitTicketBytes) / kSplitSlabBytes;
+  int best = 1;
+  double best_cost = 1.45 * nt;
+  for (int S = 2; S <= 4; S *= 2) {
+    if (nt < 8 * S || (size_t)R * S > slabs_fit || R > (int)(kSplitTicketBytes / 4)) continue;
+    const double cost = (double)((R * S + kPipeCUs - 1) / kPipeCUs) * 1.45 * nt / S + 0.16 * R * S + 3.0;
+    if (cost < 0.95 * best_cost) {
+      best_cost = cost;
+      best = S;
+    }
+  }
+  return best;
+}
+
 template <void (*KERN)(GemmF16Args)>
-static int launch_gemm_f16_pipe(const GemmF16Args& a, hipStream_t s) {
+static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_bytes, hipStream_t s) {
   const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
+  const int tiles = tiles_m * tiles_n;
   // 128 KiB of dynamic LDS needs the opt-in, once per kernel (one device per process)
   static bool opted_in = false;  // one instance per kernel
   if (!opted_in) {
@@ -504,7 +709,29 @@ static int launch_gemm_f16_pipe(const GemmF16Args& a, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
     opted_in = true;
   }
-  hipLaunchKernelGGL(KERN, dim3(tiles_m * tiles_n), dim3(512), 2 * GP_BUF, s, a);
+  int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, split_ws_bytes) : 1;
+  if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2 or 4
+    const int want = atoi(e);
+    const size_t need = kSplitTicketBytes + (size_t)(tiles % kPipeCUs) * want * kSplitSlabBytes;
+    if (want == 1 || ((want == 2 || want == 4) && split_ws && split_ws_bytes >= need &&
+                      a.M / GF_BK >= 2 * want && tiles % kPipeCUs && tiles % kPipeCUs <= 1024))
+      split = want;
+  }
+  a.split = split;
+  {
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool swiglu = a.h16 != nullptr;
+    a.wide_rows = swiglu ? (al16(a.h16) && (a.K / 2) % 8 == 0)
+                         : (al16(a.y0) && al16(a.y1) && al16(a.y2) && a.ld0 % 4 == 0 && a.ld1 % 4 == 0 &&
+                            a.ld2 % 4 == 0 && a.k0 % 4 == 0 && a.k1 % 4 == 0 && a.K % 4 == 0 &&
+                            (!a.residual || (al16(a.residual) && a.ldr % 4 == 0)));
+    if (getenv("KX_GEMM_NARROW_EPILOGUE")) a.wide_rows = 0;  // A/B runs and tests
+  }
+  a.full_tiles = split > 1 ? tiles - tiles % kPipeCUs : tiles;
+  a.tickets = static_cast<unsigned*>(split_ws);
+  a.slabs = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitTicketBytes);
+  const int grid = a.full_tiles + (tiles - a.full_tiles) * split;
+  hipLaunchKernelGGL(KERN, dim3(grid), dim3(512), 2 * GP_BUF, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -556,7 +783,8 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
                            int32_t group_size, int32_t mode, _Float16* h16, float* y0, int64_t ld0,
                            float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
                            const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
-                           char* ws, hipStream_t s, bool weights_ready = false) {
+                           char* ws, hipStream_t s, bool weights_ready = false,
+                           void* split_ws = nullptr, size_t split_ws_bytes = 0) {
   using namespace kx;
   _Float16* w16 = reinterpret_cast<_Float16*>(ws);
   float* colf = reinterpret_cast<float*>(ws + align256((size_t)K * M * 2));
@@ -575,34 +803,39 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
   // Kernel choice (KX_GEMM_F16_KERNEL = 1 / 3 forces one, for A/B runs and tests):
   //   1  128 x 128 tiles, four workgroups per CU      3  pipelined 256 x 256, one per CU
-  // The pipelined kernel is ~1.5x faster per FLOP; the small tiles only win while the large ones
-  // would leave most CUs idle AND the reduction is short (measured over T = 512..4096 on the
-  // Llama-3-8B and Qwen2.5-7B matrices: within 3 % of the better kernel except one case at 12 %).
-  // A 256 x 128 variant (two per CU) was never the fastest of the three and is gone.
+  // The pipelined kernel wins from 512 rows up on every layer matrix of Llama-3-8B, with or
+  // without cut reductions (per-layer GEMM time at 512 / 1024 / 2048 / 4096 rows: 645 / 815 / 1267 /
+  // 2454 us with the small tiles, 331 / 564 / 936 / 1448 with the large ones); the small tiles
+  // keep the reductions too short to fill its pipeline.  A 256 x 128 variant (two per CU) was never
+  // the fastest of the three and is gone.
   int choice = 0;
   if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);  // a few ns; read per call so tests can switch
-  if (choice != 1 && choice != 3) {
-    const long tiles3 = (long)((T + 255) / 256) * ((K + 255) / 256);
-    choice = M >= 512 && (tiles3 >= 144 || M >= 8192) ? 3 : 1;
-  }
+  if (choice != 1 && choice != 3) choice = M >= 512 ? 3 : 1;
   if (choice == 3)
-    return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, s)
-                  : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, s);
+    return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, split_ws, split_ws_bytes, s)
+                  : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, split_ws, split_ws_bytes, s);
   return swiglu ? launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s)
                 : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
 }
 
-extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales,
-                                    int32_t group_size, int32_t mode, void* h16, float* y0,
-                                    int64_t ld0, float* y1, int64_t ld1, float* y2, int64_t ld2,
-                                    int32_t k0, int32_t k1, const float* residual, int64_t ldr,
-                                    int32_t T, int32_t M, int32_t K, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+extern "C" size_t kx_gemm_split_workspace_bytes(void) {
+  // tickets + 768 slabs: four parts for up to 192 tiles, two parts for any partial round
+  return kx::kSplitTicketBytes + 768 * kx::kSplitSlabBytes;
+}
+
+extern "C" int kx_gemm_w8_f16act_split_ws(const void* X16, const int8_t* w, const float* scales,
+                                          int32_t group_size, int32_t mode, void* h16, float* y0,
+                                          int64_t ld0, float* y1, int64_t ld1, float* y2, int64_t ld2,
+                                          int32_t k0, int32_t k1, const float* residual, int64_t ldr,
+                                          int32_t T, int32_t M, int32_t K, void* workspace,
+                                          size_t workspace_bytes, void* split_workspace,
+                                          size_t split_workspace_bytes, void* stream) {
   if (!X16 || !w || !scales || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
   const bool weights_ready = (mode & KX_GEMM_WEIGHTS_READY) != 0;
   mode &= ~KX_GEMM_WEIGHTS_READY;
   if (!workspace || workspace_bytes < kx_gemm_w8_f16act_workspace_bytes(M, K)) return KX_EWORKSPACE;
   if (!gemm_f16_shape_ok(group_size, M, w, workspace) || (uintptr_t)X16 % 16) return KX_EUNSUPPORTED;
+  if (split_workspace && (uintptr_t)split_workspace % 256) return KX_EINVAL;
   if (mode == KX_GEMM_SWIGLU_F16) {
     // gate rows [0, K/2), up rows [K/2, K); whole blocks of 32 hidden units
     if (!h16 || K % 64 || residual) return KX_EINVAL;
@@ -617,7 +850,19 @@ extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const floa
   }
   return gemm_f16act_run(static_cast<const _Float16*>(X16), w, scales, group_size, mode,
                          static_cast<_Float16*>(h16), y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
-                         T, M, K, static_cast<char*>(workspace), (hipStream_t)stream, weights_ready);
+                         T, M, K, static_cast<char*>(workspace), (hipStream_t)stream, weights_ready,
+                         split_workspace, split_workspace_bytes);
+}
+
+extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales,
+                                    int32_t group_size, int32_t mode, void* h16, float* y0,
+                                    int64_t ld0, float* y1, int64_t ld1, float* y2, int64_t ld2,
+                                    int32_t k0, int32_t k1, const float* residual, int64_t ldr,
+                                    int32_t T, int32_t M, int32_t K, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return kx_gemm_w8_f16act_split_ws(X16, w, scales, group_size, mode, h16, y0, ld0, y1, ld1, y2, ld2, k0,
+                                    k1, residual, ldr, T, M, K, workspace, workspace_bytes, nullptr, 0,
+                                    stream);
 }
 
 extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, const float* scales,

@@ -959,7 +959,10 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
                    kx_gemm_w8_workspace_bytes(chunk, dim, 2 * hl),
                    kx_gemm_w8_workspace_bytes(chunk, hl, dim)})
     gemm_ws = b > gemm_ws ? b : gemm_ws;
-  const size_t need = act_pad + gemm_ws;
+  // and the slabs + tickets through which the GEMM combines reductions it cut into parts
+  const size_t gemm_pad = (gemm_ws + 255) / 256 * 256;
+  const size_t split_ws_bytes = kx_gemm_split_workspace_bytes();
+  const size_t need = act_pad + gemm_pad + split_ws_bytes;
   if (need > pf_bytes_) {
     KX_RET(kx_stream_sync(st));
     dev_free(pf_);
@@ -978,8 +981,10 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   float* KR = HH + (size_t)chunk * hl;  // only with a 16-bit cache
   float* VR = KR + (size_t)chunk * kl;
   void* gws = reinterpret_cast<char*>(pf_) + act_pad;
+  void* split_ws = reinterpret_cast<char*>(pf_) + act_pad + gemm_pad;
   const int gs = c.group_size;
   KX_RET(kx_stream_sync(st));
+  KX_RET(kx_memset(split_ws, 0, 4096, st));  // arrival tickets start at zero (the scratch layout moves with the chunk size)
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
   float* kbase = static_cast<float*>(kv_->get_raw_buffer_k());  // half rows when c.kv_f16
   float* vbase = static_cast<float*>(kv_->get_raw_buffer_v());
@@ -1035,10 +1040,10 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
           void* wsp = lin.w16 ? lin.w16 : gws;
           const size_t wsb = lin.w16 ? lin.w16_bytes : gemm_ws;
           const bool ready = lin.w16 ? lin.w16_ready : scratch_holds_it;
-          const int rc = kx_gemm_w8_f16act_ws(x16, static_cast<const int8_t*>(lin.w), lin.s, gs,
-                                              mode | (ready ? KX_GEMM_WEIGHTS_READY : 0), h16, y0, ld0, y1,
-                                              ld1, y2, ld2, k0, k1, resid, ldr, T_ > 0 ? T_ : rows, Mm, Kk,
-                                              wsp, wsb, st);
+          const int rc = kx_gemm_w8_f16act_split_ws(x16, static_cast<const int8_t*>(lin.w), lin.s, gs,
+                                                    mode | (ready ? KX_GEMM_WEIGHTS_READY : 0), h16, y0, ld0,
+                                                    y1, ld1, y2, ld2, k0, k1, resid, ldr, T_ > 0 ? T_ : rows,
+                                                    Mm, Kk, wsp, wsb, split_ws, split_ws_bytes, st);
           if (rc == 0 && lin.w16) lin.w16_ready = true;
           return rc;
         };

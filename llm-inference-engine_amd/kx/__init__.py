@@ -69,6 +69,10 @@ SIGNATURES = {
     "kx_gemm_w8_f16act_ws": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                        _vp, C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32,
                                        _vp, _sz, _vp]),
+    "kx_gemm_split_workspace_bytes": (_sz, []),
+    "kx_gemm_w8_f16act_split_ws": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int64, _vp, C.c_int64,
+                                             _vp, C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32,
+                                             _vp, _sz, _vp, _sz, _vp]),
     "kx_rmsnorm_f16out": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_flash_attention_f16out": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                             _i32, _f, _i32, _vp, _sz, _vp]),
@@ -365,24 +369,26 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
     return out.numpy(np.float32, q.shape)
 
 
-def gemm_w8_f16act(X16, w, s, group_size=64, swiglu=False):
-    """fp16 activations [T][M]; fp32 [T][K] out, or fp16 silu(gate)*up [T][K/2] with swiglu."""
+def gemm_w8_f16act(X16, w, s, group_size=64, swiglu=False, split_ws=None):
+    """fp16 activations [T][M]; fp32 [T][K] out, or fp16 silu(gate)*up [T][K/2] with swiglu.
+    split_ws: a zero-filled Buf of kx_gemm_split_workspace_bytes() lets the kernel cut reductions."""
     K, M = w.shape
     T = X16.shape[0]
     dx, dw, ds = Buf.from_numpy(X16.astype(np.float16)), Buf.from_numpy(w.astype(np.int8)), \
         Buf.from_numpy(s.astype(np.float32))
     wsb = lib().kx_gemm_w8_f16act_workspace_bytes(M, K)
     ws = Buf(wsb)
+    sp, spb = (split_ws.ptr, split_ws.nbytes) if split_ws is not None else (None, 0)
     if swiglu:
         h = Buf.zeros((T, K // 2), np.float16)
-        check(lib().kx_gemm_w8_f16act_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 1, h.ptr, None, 0, None,
-                                         0, None, 0, 0, 0, None, 0, T, M, K, ws.ptr, wsb, None),
-              "kx_gemm_w8_f16act_ws")
+        check(lib().kx_gemm_w8_f16act_split_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 1, h.ptr, None, 0, None,
+                                               0, None, 0, 0, 0, None, 0, T, M, K, ws.ptr, wsb, sp, spb, None),
+              "kx_gemm_w8_f16act_split_ws")
         return h.numpy(np.float16, (T, K // 2))
     dy = Buf.zeros((T, K))
-    check(lib().kx_gemm_w8_f16act_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 0, None, dy.ptr, K, None, 0,
-                                     None, 0, K, K, None, 0, T, M, K, ws.ptr, wsb, None),
-          "kx_gemm_w8_f16act_ws")
+    check(lib().kx_gemm_w8_f16act_split_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 0, None, dy.ptr, K, None, 0,
+                                           None, 0, K, K, None, 0, T, M, K, ws.ptr, wsb, sp, spb, None),
+          "kx_gemm_w8_f16act_split_ws")
     return dy.numpy(np.float32, (T, K))
 
 

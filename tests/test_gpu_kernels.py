@@ -607,6 +607,41 @@ def test_gemm_w8_f16_every_tile_kernel(monkeypatch, choice, T, K, M):
     assert np.all(np.abs(got - want) <= 2.0 ** -11 * absum + 1e-7 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("T,K,M", [(520, 600, 1024), (300, 256, 512), (4352, 4096, 512)])
+def test_gemm_w8_f16_reduction_cut_over_idle_cus(monkeypatch, T, K, M):
+    # a last, partial round of 256 x 256 tiles has its reduction cut into 2 or 4 parts that meet
+    # in fp32 slabs: same result as the uncut kernel up to fp32 re-association, bitwise repeatable,
+    # tickets back at zero; (4352, 4096): 16 cut tiles behind 256 whole ones
+    monkeypatch.setenv("KX_GEMM_F16_KERNEL", "3")
+    rng = np.random.default_rng(T + M)
+    _, w, s = rand_w8(rng, K, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    absum = np.abs(X16.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(K, M) *
+                                               np.abs(w.astype(np.float64))).T
+    monkeypatch.setenv("KX_GEMM_SPLIT", "1")
+    base = kx.gemm_w8_f16act(X16, w, s, GS)
+    rows = np.unique(np.r_[0, T - 1, rng.integers(0, T, 6)])
+    want = kxo.gemm_w8(X16[rows].astype(np.float32), w, s, GS, threads=8)
+    assert np.all(np.abs(base[rows] - want) <= 2.0 ** -11 * absum[rows] + 1e-7 * np.abs(want).max())
+    sp = kx.Buf.zeros(kx.lib().kx_gemm_split_workspace_bytes(), np.uint8)
+    for parts in ("2", "4"):
+        monkeypatch.setenv("KX_GEMM_SPLIT", parts)
+        got = kx.gemm_w8_f16act(X16, w, s, GS, split_ws=sp)
+        assert np.all(np.abs(got - base) <= 1e-6 * absum + 1e-7 * np.abs(base).max())
+        assert not np.array_equal(got, base) or M // 64 < 2 * int(parts)   # the cut really happened
+        again = kx.gemm_w8_f16act(X16, w, s, GS, split_ws=sp)
+        assert np.array_equal(got, again)
+        assert not sp.numpy(np.uint8, (4096,)).any()
+        if K % 64 == 0:
+            h = kx.gemm_w8_f16act(X16, w, s, GS, swiglu=True, split_ws=sp).astype(np.float32)
+            monkeypatch.setenv("KX_GEMM_SPLIT", "1")
+            h1 = kx.gemm_w8_f16act(X16, w, s, GS, swiglu=True).astype(np.float32)
+            assert np.all(np.abs(h - h1) <= 2.0 ** -9 * np.abs(h1) + 1e-5)
+    # no split workspace: the request is ignored, the plain kernel runs
+    monkeypatch.setenv("KX_GEMM_SPLIT", "2")
+    assert np.array_equal(kx.gemm_w8_f16act(X16, w, s, GS), base)
+
+
 def test_gemm_w8_f16_activations_preconditions():
     L = kx.lib()
     T, K, M = 256, 128, 128
