@@ -188,6 +188,21 @@ int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales, 
  * on arrival order).  The first 4096 bytes (arrival tickets) must be ZERO before the first use and
  * are left zero by every call; calls that share it must not overlap.  NULL: never cut. */
 size_t kx_gemm_split_workspace_bytes(void);
+/* The Wq|Wk|Wv product of a prompt chunk with what follows it folded into the GEMM's epilogue
+ * (attention_qkv + the RoPE layer, llama3.cpp:654-677; the reference runs them as separate
+ * kernels, one row at a time): bias (K = q_dim + 2 kv_dim values, or NULL) added ahead of the
+ * rotation as MatmulLayer does (matmul.cpp:76-79), q columns to q[t][ld_q], k and v columns to
+ * the given rows (the KV-cache rows of positions pos0 .. pos0 + T - 1), and q and k rotated for
+ * position pos0 + t with the sin/cos tables of kx_sin_cos_cache_f32.  head_size 64 or 128,
+ * 16-byte aligned rows; KX_EUNSUPPORTED otherwise (run kx_gemm_w8_f16act_ws + kx_rope_bias_f32). */
+int kx_gemm_w8_f16act_qkv_rope(const void* X16, const int8_t* w, const float* scales,
+                               int32_t group_size, int32_t weights_ready, float* q, int64_t ld_q,
+                               float* k, int64_t ld_k, float* v, int64_t ld_v, int32_t q_dim,
+                               int32_t kv_dim, int32_t head_size, int32_t rope_variant,
+                               const float* sin_cache, const float* cos_cache, int32_t pos0,
+                               const float* bias, int32_t T, int32_t M, void* workspace,
+                               size_t workspace_bytes, void* split_workspace,
+                               size_t split_workspace_bytes, void* stream);
 int kx_gemm_w8_f16act_split_ws(const void* X16, const int8_t* w, const float* scales,
                                int32_t group_size, int32_t mode, void* h16, float* y0, int64_t ld0,
                                float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,

@@ -40,6 +40,12 @@ struct GemmF16Args {
   unsigned* tickets;
   int32_t full_tiles, split;
   int32_t wide_rows;  // every destination row is 16-byte aligned: the epilogue may use 16-byte accesses
+  // Wq|Wk|Wv form (pipelined kernel, wide rows): bias (all K columns, or null), then the rotary
+  // embedding of the q columns [0, k0) and the k columns [k0, k1) at position pos0 + row
+  const float* bias;
+  const float* sin_cache;  // [position][head_size], the entry of a pair at its even index
+  const float* cos_cache;
+  int32_t rope_variant, head_size, pos0;  // rope_variant < 0: bias only
 };
 
 // X fp32 [T][ldx] -> fp16 [T][ldy], M columns
@@ -426,7 +432,7 @@ __device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t,
 // workgroup barrier is needed between its writes and reads.  The 16-column blocks of a row are
 // stored XOR-ed with the row's quad index, which spreads a write instruction over all banks.
 // Needs 16-byte aligned rows in every destination; the caller falls back to the dword form.
-template <bool SWIGLU>
+template <bool SWIGLU, bool ROPE>
 __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, const f32x4 (&acc)[8][4],
                                                        char* smem, int trow0, int ncol0, int wave, int lane) {
   const int c16 = lane & 15, g = lane >> 4;
@@ -464,11 +470,12 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
     return;
   } else {
     float* wb = reinterpret_cast<float*>(smem) + wave * 4096;
-    float f[4];
+    float f[4], bias[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = ncol0 + ni * 16 + c16;
       f[ni] = n < a.K ? a.colf[n] : 0.f;
+      bias[ni] = ROPE && a.bias && n < a.K ? a.bias[n] : 0.f;
     }
     // this lane's four columns when reading back, and where they go
     const int n4 = ncol0 + 4 * c16;
@@ -483,20 +490,54 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
     } else {
       dst = a.y2; ld = a.ld2; col = n4 - a.k1;
     }
+    // rotary embedding (ROPE form): the columns of q and k turn with their pair partner.  Pairs
+    // are (2i, 2i+1) of a head (interleaved, rope_kernel.cu:98-128) or (i, i + hs/2) (half-split,
+    // :5-36); the half-split partner sits 32 columns away inside this wave's block for 64-wide
+    // heads and at the same place in the neighbouring wave's block for 128-wide heads.
+    const bool turn = ROPE && a.rope_variant >= 0 && n4 < a.k1;
+    const int d = col % a.head_size;                    // first of this lane's columns inside its head
+    const bool split = a.rope_variant == KX_ROPE_HALF_SPLIT;
+    const int hhalf = a.head_size >> 1;
+    const bool low = d < hhalf;
+    const int tab = split ? 2 * (low ? d : d - hhalf) : d;  // table index of the first pair
+    const float* pb = a.head_size == 128 ? reinterpret_cast<float*>(smem) + (wave ^ 1) * 4096 : wb;
+    const int pcol = a.head_size == 128 ? 4 * c16 : (4 * c16) ^ 32;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      if (ROPE && half) __syncthreads();  // the neighbour's reads of the first half are over
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            wb[(m4 * 16 + 4 * g + r) * 64 + ((ni * 16 + c16) ^ (16 * g))] = acc[half * 4 + m4][ni][r] * f[ni];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wb[(m4 * 16 + 4 * g + r) * 64 + ((ni * 16 + c16) ^ (16 * g))] =
+                acc[half * 4 + m4][ni][r] * f[ni] + bias[ni];
+      if (ROPE) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + g, t = trow0 + half * 64 + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(wb + row * 64 + ((4 * c16) ^ (16 * ((row >> 2) & 3))));
+        const int sw = 16 * ((row >> 2) & 3);
+        f32x4 v = *reinterpret_cast<const f32x4*>(wb + row * 64 + ((4 * c16) ^ sw));
+        if (turn) {
+          const size_t trow = (size_t)(a.pos0 + min(t, a.T - 1)) * a.head_size + tab;
+          if (split) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pb + row * 64 + (pcol ^ sw));
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.sin_cache + trow);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.sin_cache + trow + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.cos_cache + trow);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.cos_cache + trow + 4);
+            const f32x4 sn = {s0.x, s0.z, s1.x, s1.z}, cs = {c0.x, c0.z, c1.x, c1.z};
+            // x_lo' = x_lo cos - x_hi sin ; x_hi' = x_lo sin + x_hi cos
+            v = low ? v * cs - pv * sn : pv * sn + v * cs;
+          } else {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.sin_cache + trow);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.cos_cache + trow);
+            v = f32x4{v.x * c0.x - v.y * s0.x, v.x * s0.x + v.y * c0.x,
+                      v.z * c0.z - v.w * s0.z, v.z * s0.z + v.w * c0.z};
+          }
+        }
         if (t < a.T && n4 < a.K) {
           if (add_res) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + (size_t)t * a.ldr + col);
@@ -537,7 +578,7 @@ __device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_r
   }
 }
 
-template <bool SWIGLU>
+template <bool SWIGLU, bool ROPE = false>
 __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -661,7 +702,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   }
   if (a.wide_rows) {
     __syncthreads();  // every wave's last tile reads and LDS-DMA landings are over: LDS is free
-    gemm_pipe_epilogue_lds<SWIGLU>(a, acc, smem, t0 + wr * 128, n0 + wc * 64, wave, lane);
+    gemm_pipe_epilogue_lds<SWIGLU, ROPE>(a, acc, smem, t0 + wr * 128, n0 + wc * 64, wave, lane);
   } else {
     gemm_f16_epilogue16<8, 4, SWIGLU>(a, acc, t0 + wr * 128, n0 + wc * 64, lane);
   }
@@ -669,6 +710,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
 
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true>(a); }
+__global__ __launch_bounds__(512, 1) void gemm_f16_pipe_qkv_rope_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false, true>(a); }
 
 // Split workspace: kSplitTicketBytes of arrival tickets (one per tile of the last, partial round),
 // then 256 KiB slabs.
@@ -699,7 +741,8 @@ static int pipe_split_choice(int tiles, int nt, size_t split_ws_bytes) {
 }
 
 template <void (*KERN)(GemmF16Args)>
-static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_bytes, hipStream_t s) {
+static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_bytes, hipStream_t s,
+                                bool need_wide = false) {
   const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
   const int tiles = tiles_m * tiles_n;
   // 128 KiB of dynamic LDS needs the opt-in, once per kernel (one device per process)
@@ -725,7 +768,8 @@ static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_b
                          : (al16(a.y0) && al16(a.y1) && al16(a.y2) && a.ld0 % 4 == 0 && a.ld1 % 4 == 0 &&
                             a.ld2 % 4 == 0 && a.k0 % 4 == 0 && a.k1 % 4 == 0 && a.K % 4 == 0 &&
                             (!a.residual || (al16(a.residual) && a.ldr % 4 == 0)));
-    if (getenv("KX_GEMM_NARROW_EPILOGUE")) a.wide_rows = 0;  // A/B runs and tests
+    if (getenv("KX_GEMM_NARROW_EPILOGUE") && !need_wide) a.wide_rows = 0;  // A/B runs and tests
+    if (need_wide && !a.wide_rows) return KX_EUNSUPPORTED;
   }
   a.full_tiles = split > 1 ? tiles - tiles % kPipeCUs : tiles;
   a.tickets = static_cast<unsigned*>(split_ws);
@@ -784,7 +828,8 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
                            float* y1, int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1,
                            const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
                            char* ws, hipStream_t s, bool weights_ready = false,
-                           void* split_ws = nullptr, size_t split_ws_bytes = 0) {
+                           void* split_ws = nullptr, size_t split_ws_bytes = 0,
+                           const kx::GemmF16Args* qkv_form = nullptr) {
   using namespace kx;
   _Float16* w16 = reinterpret_cast<_Float16*>(ws);
   float* colf = reinterpret_cast<float*>(ws + align256((size_t)K * M * 2));
@@ -801,6 +846,11 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
   a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
   a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
+  a.rope_variant = -1;
+  if (qkv_form) {
+    a.bias = qkv_form->bias; a.sin_cache = qkv_form->sin_cache; a.cos_cache = qkv_form->cos_cache;
+    a.rope_variant = qkv_form->rope_variant; a.head_size = qkv_form->head_size; a.pos0 = qkv_form->pos0;
+  }
   // Kernel choice (KX_GEMM_F16_KERNEL = 1 / 3 forces one, for A/B runs and tests):
   //   1  128 x 128 tiles, four workgroups per CU      3  pipelined 256 x 256, one per CU
   // The pipelined kernel wins from 512 rows up on every layer matrix of Llama-3-8B, with or
@@ -811,6 +861,8 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   int choice = 0;
   if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);  // a few ns; read per call so tests can switch
   if (choice != 1 && choice != 3) choice = M >= 512 ? 3 : 1;
+  if (qkv_form)  // only the pipelined kernel has this epilogue; the caller checked the shape
+    return launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_kernel>(a, split_ws, split_ws_bytes, s, true);
   if (choice == 3)
     return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, split_ws, split_ws_bytes, s)
                   : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, split_ws, split_ws_bytes, s);
@@ -852,6 +904,35 @@ extern "C" int kx_gemm_w8_f16act_split_ws(const void* X16, const int8_t* w, cons
                          static_cast<_Float16*>(h16), y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
                          T, M, K, static_cast<char*>(workspace), (hipStream_t)stream, weights_ready,
                          split_workspace, split_workspace_bytes);
+}
+
+extern "C" int kx_gemm_w8_f16act_qkv_rope(const void* X16, const int8_t* w, const float* scales,
+                                          int32_t group_size, int32_t weights_ready, float* q,
+                                          int64_t ld_q, float* k, int64_t ld_k, float* v, int64_t ld_v,
+                                          int32_t q_dim, int32_t kv_dim, int32_t head_size,
+                                          int32_t rope_variant, const float* sin_cache,
+                                          const float* cos_cache, int32_t pos0, const float* bias,
+                                          int32_t T, int32_t M, void* workspace, size_t workspace_bytes,
+                                          void* split_workspace, size_t split_workspace_bytes,
+                                          void* stream) {
+  if (!X16 || !w || !scales || !q || !k || !v || !sin_cache || !cos_cache) return KX_EINVAL;
+  if (T <= 0 || M <= 0 || q_dim <= 0 || kv_dim <= 0 || group_size <= 0 || pos0 < 0) return KX_EINVAL;
+  if (rope_variant != KX_ROPE_INTERLEAVED && rope_variant != KX_ROPE_HALF_SPLIT) return KX_EINVAL;
+  const int32_t K = q_dim + 2 * kv_dim;
+  if (!workspace || workspace_bytes < kx_gemm_w8_f16act_workspace_bytes(M, K)) return KX_EWORKSPACE;
+  if (!gemm_f16_shape_ok(group_size, M, w, workspace) || (uintptr_t)X16 % 16) return KX_EUNSUPPORTED;
+  // whole heads per 64-column wave block (64) or per pair of them (128); tables read 16 bytes at a time
+  if ((head_size != 64 && head_size != 128) || q_dim % head_size || kv_dim % head_size ||
+      ((uintptr_t)sin_cache | (uintptr_t)cos_cache) % 16 || (bias && (uintptr_t)bias % 4))
+    return KX_EUNSUPPORTED;
+  if (split_workspace && (uintptr_t)split_workspace % 256) return KX_EINVAL;
+  kx::GemmF16Args form{};
+  form.bias = bias; form.sin_cache = sin_cache; form.cos_cache = cos_cache;
+  form.rope_variant = rope_variant; form.head_size = head_size; form.pos0 = pos0;
+  return gemm_f16act_run(static_cast<const _Float16*>(X16), w, scales, group_size, KX_GEMM_ROUTE_F32,
+                         nullptr, q, ld_q, k, ld_k, v, ld_v, q_dim, q_dim + kv_dim, nullptr, 0, T, M, K,
+                         static_cast<char*>(workspace), (hipStream_t)stream, weights_ready != 0,
+                         split_workspace, split_workspace_bytes, &form);
 }
 
 extern "C" int kx_gemm_w8_f16act_ws(const void* X16, const int8_t* w, const float* scales,

@@ -1068,10 +1068,22 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
         // long chunks keep the GEMM inputs in fp16: the norm and the attention kernel write fp16,
         // SwiGLU runs in the epilogue of the W1|W3 GEMM; XN / ATT / HH are reused as fp16 rows
         KX_RET(kx_rmsnorm_f16out(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
-        KX_RET(gemm16(XN, lw.qkv, KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
-                      nullptr, 0, dim, lw.qkv.rows));
-        KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
-                                p0, rows, sin_, cos_, st));
+        if (c.head_size == 64 || c.head_size == 128) {
+          // bias, RoPE and the K/V row placement ride in the epilogue of the Wq|Wk|Wv product
+          Linear& lin = lw.qkv;
+          void* wsp = lin.w16 ? lin.w16 : gws;
+          const size_t wsb = lin.w16 ? lin.w16_bytes : gemm_ws;
+          const bool ready = lin.w16 && lin.w16_ready;
+          KX_RET(kx_gemm_w8_f16act_qkv_rope(XN, static_cast<const int8_t*>(lin.w), lin.s, gs, ready, Q, ql, krow,
+                                            kl, vrow, kl, ql, kl, c.head_size, c.rope_variant, sin_, cos_, p0,
+                                            bq, rows, dim, wsp, wsb, split_ws, split_ws_bytes, st));
+          if (lin.w16) lin.w16_ready = true;
+        } else {
+          KX_RET(gemm16(XN, lw.qkv, KX_GEMM_ROUTE_F32, nullptr, Q, ql, krow, kl, vrow, kl, ql, ql + kl,
+                        nullptr, 0, dim, lw.qkv.rows));
+          KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
+                                  p0, rows, sin_, cos_, st));
+        }
         if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
         KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
         ST_RET(row_parallel(ATT, ql, lw.wo, ql));

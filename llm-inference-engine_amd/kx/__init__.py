@@ -70,6 +70,9 @@ SIGNATURES = {
                                        _vp, C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32,
                                        _vp, _sz, _vp]),
     "kx_gemm_split_workspace_bytes": (_sz, []),
+    "kx_gemm_w8_f16act_qkv_rope": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
+                                             C.c_int64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32,
+                                             _i32, _vp, _sz, _vp, _sz, _vp]),
     "kx_gemm_w8_f16act_split_ws": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                              _vp, C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32,
                                              _vp, _sz, _vp, _sz, _vp]),

@@ -642,6 +642,54 @@ def test_gemm_w8_f16_reduction_cut_over_idle_cus(monkeypatch, T, K, M):
     assert np.array_equal(kx.gemm_w8_f16act(X16, w, s, GS), base)
 
 
+@pytest.mark.parametrize("hs,variant,T,pos0,with_bias", [(128, 1, 300, 5, False), (64, 1, 530, 0, True),
+                                                         (64, 0, 260, 17, True), (128, 0, 256, 3, False)])
+def test_gemm_w8_f16_qkv_with_bias_and_rope_in_the_epilogue(hs, variant, T, pos0, with_bias):
+    # one launch = product + bias + rotary embedding + q / K-row / V-row placement; checked against
+    # the plain product (same kernel, plain epilogue) followed by the oracle's bias-then-rope
+    rng = np.random.default_rng(hs + T)
+    L = kx.lib()
+    M, H, KVH = 256, 4, 2
+    ql, kl = H * hs, KVH * hs
+    K = ql + 2 * kl
+    _, w, s = rand_w8(rng, K, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    bias = rng.standard_normal(K).astype(np.float32) * 0.1 if with_bias else None
+    S = pos0 + T + 3
+    ds_, dc_ = kx.Buf.zeros((S, hs)), kx.Buf.zeros((S, hs))
+    kx.check(L.kx_sin_cos_cache_f32(hs, S, 10000.0, ds_.ptr, dc_.ptr, None))
+    s_tab, c_tab = ds_.numpy(), dc_.numpy()
+    plain = kx.gemm_w8_f16act(X16, w, s, GS)
+    if with_bias:
+        plain = plain + bias
+    dx, dw, dsc = kx.Buf.from_numpy(X16), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)
+    q = kx.Buf.zeros((T, ql))
+    kst = kl + 64                                       # K / V rows live in a wider cache
+    kc, vc = kx.Buf.from_numpy(np.full((S, kst), 7.0, np.float32)), kx.Buf.from_numpy(np.full((S, kst), 9.0, np.float32))
+    db = kx.Buf.from_numpy(bias) if with_bias else None
+    wsb = L.kx_gemm_w8_f16act_workspace_bytes(M, K)
+    ws = kx.Buf(wsb)
+    sp = kx.Buf.zeros(L.kx_gemm_split_workspace_bytes(), np.uint8)
+    kx.check(L.kx_gemm_w8_f16act_qkv_rope(dx.ptr, dw.ptr, dsc.ptr, GS, 0, q.ptr, ql, kc.at(pos0 * kst * 4), kst,
+                                          vc.at(pos0 * kst * 4), kst, ql, kl, hs, variant, ds_.ptr, dc_.ptr, pos0,
+                                          db.ptr if db else None, T, M, ws.ptr, wsb, sp.ptr, sp.nbytes, None))
+    gq, gk, gv = q.numpy(), kc.numpy(), vc.numpy()
+    tol = 2e-5 * np.abs(plain).max()
+    for r in range(T):
+        wq, wk = kxo.rope(variant, ql, kl, hs, plain[r, :ql].copy(), plain[r, ql:ql + kl].copy(), pos0 + r,
+                          s_tab, c_tab)
+        np.testing.assert_allclose(gq[r], wq, rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(gk[pos0 + r, :kl], wk, rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(gv[pos0 + r, :kl], plain[r, ql + kl:], rtol=1e-6, atol=tol)
+    # rows outside the chunk and the padding beside the rows are untouched
+    assert np.all(gk[:pos0] == 7.0) and np.all(gk[pos0 + T:] == 7.0) and np.all(gk[:, kl:] == 7.0)
+    assert np.all(gv[:pos0] == 9.0) and np.all(gv[pos0 + T:] == 9.0) and np.all(gv[:, kl:] == 9.0)
+    # head sizes the epilogue is not laid out for are refused, not mangled
+    assert L.kx_gemm_w8_f16act_qkv_rope(dx.ptr, dw.ptr, dsc.ptr, GS, 0, q.ptr, ql, kc.ptr, kst, vc.ptr, kst, ql, kl,
+                                        32, variant, ds_.ptr, dc_.ptr, 0, None, T, M, ws.ptr, wsb, None, 0,
+                                        None) == -2
+
+
 def test_gemm_w8_f16_activations_preconditions():
     L = kx.lib()
     T, K, M = 256, 128, 128
