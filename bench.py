@@ -114,6 +114,62 @@ def prefill_kernels(kx, shape, tp, T=4096):
         kx.check(L.kx_gemm_w8_f16act_ws(X16.ptr, w.ptr, sc.ptr, 64, 1, H16.ptr, None, 0, None, 0, None,
                                         0, 0, 0, None, 0, T, M, K, gws.ptr, gwsb, st.ptr), "gemm_f16act")
     fused_us = kx.time_graph(st, gemm_swiglu, replays=5) if K % 64 == 0 and T >= 256 else None
+
+    # The four GEMMs of one layer as the prompt pass runs them from its second pass on: fp16 rows
+    # in, the fp16 image of the weights kept from the first pass (no dequantisation pass), bias /
+    # RoPE / SwiGLU / residual in the epilogues, reductions of a partial last round of tiles cut
+    # over idle CUs.
+    layer = None
+    hs_ok = hs in (64, 128)
+    if fused_us is not None and hs_ok:
+        dim, hl = M, K // 2
+        ql, kl = H * hs, KVH * hs
+        S = T + 64
+        sin_t, cos_t = kx.Buf(S * hs * 4), kx.Buf(S * hs * 4)
+        kx.check(L.kx_sin_cos_cache_f32(hs, S, 500000.0, sin_t.ptr, cos_t.ptr, st.ptr), "sin_cos")
+        spb = L.kx_gemm_split_workspace_bytes()
+        sp = kx.Buf.zeros(spb, np.uint8)
+        Q = kx.Buf(T * ql * 4)
+        res = kx.Buf(T * dim * 4)
+        Xo = kx.Buf(T * dim * 4)
+        A16 = kx.Buf(T * max(ql, hl) * 2)
+        kx.check(L.kx_fill_hash_f32(res.ptr, T, dim, dim, 0, 0, 11, -1.0, 1.0, st.ptr), "fill")
+        mats = {}
+        for name, (rows_, cols_) in {"qkv": (ql + 2 * kl, dim), "wo": (dim, ql), "w13": (2 * hl, dim),
+                                     "w2": (dim, hl)}.items():
+            wm, sm = kx.Buf(rows_ * cols_), kx.Buf(rows_ * cols_ // 64 * 4)
+            kx.check(L.kx_fill_hash_i8(wm.ptr, rows_, cols_, cols_, 0, 0, 21, st.ptr), "fill")
+            kx.check(L.kx_fill_hash_f32(sm.ptr, rows_, cols_ // 64, cols_ // 64, 0, 0, 22, 1e-4, 3e-4, st.ptr), "fill")
+            wsb_ = L.kx_gemm_w8_f16act_workspace_bytes(cols_, rows_)
+            mats[name] = (wm, sm, kx.Buf(wsb_), wsb_, rows_, cols_)
+
+        def run_layer(ready):
+            f = 0x100 if ready else 0
+            wm, sm, ws_, wsb_, rows_, cols_ = mats["qkv"]
+            kx.check(L.kx_gemm_w8_f16act_qkv_rope(X16.ptr, wm.ptr, sm.ptr, 64, 1 if ready else 0, Q.ptr, ql, kc.ptr,
+                                                  kl, vc.ptr, kl, ql, kl, hs, 1, sin_t.ptr, cos_t.ptr, 0, None, T,
+                                                  dim, ws_.ptr, wsb_, sp.ptr, spb, st.ptr), "qkv_rope")
+            wm, sm, ws_, wsb_, rows_, cols_ = mats["wo"]
+            kx.check(L.kx_gemm_w8_f16act_split_ws(A16.ptr, wm.ptr, sm.ptr, 64, f, None, Xo.ptr, dim, None, 0, None, 0,
+                                                  dim, dim, res.ptr, dim, T, cols_, rows_, ws_.ptr, wsb_, sp.ptr, spb,
+                                                  st.ptr), "wo")
+            wm, sm, ws_, wsb_, rows_, cols_ = mats["w13"]
+            kx.check(L.kx_gemm_w8_f16act_split_ws(X16.ptr, wm.ptr, sm.ptr, 64, 1 | f, H16.ptr, None, 0, None, 0, None,
+                                                  0, 0, 0, None, 0, T, cols_, rows_, ws_.ptr, wsb_, sp.ptr, spb,
+                                                  st.ptr), "w13")
+            wm, sm, ws_, wsb_, rows_, cols_ = mats["w2"]
+            kx.check(L.kx_gemm_w8_f16act_split_ws(H16.ptr, wm.ptr, sm.ptr, 64, f, None, Xo.ptr, dim, None, 0, None, 0,
+                                                  dim, dim, res.ptr, dim, T, cols_, rows_, ws_.ptr, wsb_, sp.ptr, spb,
+                                                  st.ptr), "w2")
+        kx.check(L.kx_memset(A16.ptr, 0, T * max(ql, hl) * 2, st.ptr), "memset")
+        run_layer(False)
+        st.sync()
+        layer_us = kx.time_graph(st, lambda: run_layer(True), replays=5)
+        layer_flops = 2.0 * T * dim * (ql + 2 * kl + ql + 2 * hl + hl)
+        layer = {"T": T, "us": layer_us, "tflops": layer_flops / layer_us / 1e6,
+                 "mfma_util": layer_flops / layer_us / 1e6 / MFMA_F16_PEAK_TFLOPS,
+                 "what": "Wq|Wk|Wv (+RoPE), Wo (+residual), W1|W3 (+SwiGLU), W2 (+residual) of one layer, "
+                         "fp16 weight images kept"}
     return {
         "flash_attention": {"rows": T, "heads": H, "head_size": hs, "us": fa_us,
                             "tflops": fa_flops / fa_us / 1e6,
@@ -123,6 +179,7 @@ def prefill_kernels(kx, shape, tp, T=4096):
         "gemm_w8_f16_swiglu": None if fused_us is None else {
             "T": T, "K": K, "M": M, "us": fused_us, "tflops": gemm_flops / fused_us / 1e6,
             "mfma_util": gemm_flops / fused_us / 1e6 / MFMA_F16_PEAK_TFLOPS},
+        "layer_gemms_kept_weights": layer,
         "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
     }
 

@@ -21,6 +21,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 rm -f $O/prof/b_kernel_trace.csv
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 8 --warmup 2 $B > /dev/null 2> $O/pmcf.err
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 8 --warmup 2 $B > /dev/null 2> $O/pmcw.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_prefill -o p -- python3 $R/tools/bench_prefill_model.py llama-3-8b 4096 3 > $O/prefill_model.txt 2> $O/prefill_model.err
+rm -f $O/prof_prefill/p_kernel_trace.csv
+timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python3 $R/tools/bench_prefill.py > $O/prefill_kernels.json 2> $O/pmcm.err
 cd $R
+python tools/collect_mfma.py $O/pmc_mfma/m_counter_collection.csv $O/prefill_mfma.json > /dev/null
+rm -rf $O/pmc_mfma
 python tools/collect_traffic.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $O/traffic.json
 rm -rf $O/pmc_fetch $O/pmc_write
