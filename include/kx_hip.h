@@ -226,6 +226,9 @@ int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, 
  * probabilities the reference leaves in it are not reproduced (nothing reads them,
  * llama3.cpp:724-733). */
 size_t kx_attn_workspace_bytes(int32_t head_num, int32_t head_size);
+/* Arrival tickets of a split workspace back to zero (its state after allocation + memset): the way
+ * to recover a workspace after a launch that used it was aborted.  No reference counterpart. */
+int kx_attn_workspace_reset(void* workspace, size_t workspace_bytes, void* stream);
 int kx_mha_decode_f32(const float* query, const float* key_cache, const float* value_cache,
                       float* out, int32_t pos, int32_t head_num, int32_t kv_mul, int32_t head_size,
                       int32_t kv_dim, int32_t seq_len, int32_t layer_index, void* workspace,

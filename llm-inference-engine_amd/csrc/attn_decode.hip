@@ -752,6 +752,14 @@ static __device__ __align__(256) unsigned char scratch[kx::kStaticScratchBytes];
 static void* g_scratch_ptr[kx::kMaxDevices];
 static std::mutex g_scratch_mutex;
 
+// Puts a split workspace back into its initial state (arrival tickets at zero), e.g. after a
+// launch that used it was aborted midway.
+extern "C" int kx_attn_workspace_reset(void* workspace, size_t workspace_bytes, void* stream) {
+  if (!workspace || workspace_bytes < kx::kTicketBytes) return KX_EINVAL;
+  KX_HIP_TRY(hipMemsetAsync(workspace, 0, kx::kTicketBytes, (hipStream_t)stream));
+  return KX_OK;
+}
+
 extern "C" size_t kx_mha_decode_static_limit_bytes(void) { return kx::kStaticScratchBytes; }
 
 extern "C" int kx_mha_decode_static_f32(const float* query, const float* key_cache,

@@ -415,12 +415,10 @@ template <int HS, bool F16SRC>
 static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
   constexpr int vt_row = F16SRC ? FA_VT_ROW16 : FA_VT_ROW;
   constexpr size_t lds = 2 * (size_t)(FA_KV * (HS + 8) + HS * vt_row) * 2;
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
+  static OncePerDevice raised;
+  if (lds > 64 * 1024 && raised.first())
     KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, F16SRC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = true;
-  }
   const dim3 grid(kvh * (a.kv_mul / a.hpb), qblocks);
   hipLaunchKernelGGL((attn_prefill_kernel<HS, F16SRC>), grid, dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();

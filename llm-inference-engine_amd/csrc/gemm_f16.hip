@@ -745,13 +745,11 @@ static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_b
                                 bool need_wide = false) {
   const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
   const int tiles = tiles_m * tiles_n;
-  // 128 KiB of dynamic LDS needs the opt-in, once per kernel (one device per process)
-  static bool opted_in = false;  // one instance per kernel
-  if (!opted_in) {
+  // 128 KiB of dynamic LDS needs the opt-in, once per kernel and device
+  static OncePerDevice opted_in;  // one instance per kernel
+  if (opted_in.first())
     KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
-    opted_in = true;
-  }
   int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, split_ws_bytes) : 1;
   if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2 or 4
     const int want = atoi(e);

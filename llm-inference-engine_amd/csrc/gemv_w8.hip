@@ -445,12 +445,10 @@ static int launch(const GemvW8Args& a, int threads, hipStream_t s) {
   const int grid = (out_rows + a.rows_per_block - 1) / a.rows_per_block;
   const size_t lds = (size_t)a.chunks * 1024 * sizeof(float);
   if (lds > 64 * 1024) {
-    static bool raised = false;  // per instantiation; the attribute is sticky
-    if (!raised) {
+    static OncePerDevice raised;  // per instantiation; the attribute is sticky
+    if (raised.first())
       KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_w8_kernel<R, U, MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-      raised = true;
-    }
   }
   hipLaunchKernelGGL((gemv_w8_kernel<R, U, MODE>), dim3(grid), dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();

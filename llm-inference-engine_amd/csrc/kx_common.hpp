@@ -5,6 +5,19 @@
 
 #include "../../include/kx_hip.h"
 
+// A kernel's raised dynamic-LDS limit (hipFuncSetAttribute) holds for the device that was current
+// when it was set: one flag per device and call site.  first() is true once per device.
+struct OncePerDevice {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;  // unknown: set it again
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 #define KX_HIP_TRY(expr)                        \
   do {                                          \
     hipError_t e_ = (expr);                     \

@@ -81,6 +81,7 @@ SIGNATURES = {
                                             _i32, _f, _i32, _vp, _sz, _vp]),
     "kx_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "kx_attn_workspace_bytes": (_sz, [_i32, _i32]),
+    "kx_attn_workspace_reset": (C.c_int, [_vp, _sz, _vp]),
     "kx_flash_attention_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "kx_mha_decode_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _sz, _vp]),

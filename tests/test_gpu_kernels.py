@@ -290,6 +290,18 @@ def test_mha_decode_device_position_one_workspace_many_launches():
         np.testing.assert_allclose(out.numpy(np.float32, (H, hs)), want, rtol=0, atol=2e-5,
                                    err_msg=f"pos={pos}")
     assert not ws.numpy(np.uint8, (wsb,))[:16384].any()  # tickets are back at zero
+    # a workspace left dirty (as by a launch aborted midway) is put right by the reset entry
+    dirty = np.zeros(wsb, np.uint8)
+    dirty[:16384] = rng.integers(1, 255, 16384)
+    ws.upload(dirty)
+    kx.check(L.kx_attn_workspace_reset(ws.ptr, wsb, None))
+    pos_dev.upload(np.array([3000], np.int32))
+    kx.check(L.kx_mha_decode_dpos_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H, H // KVH, hs, kvd,
+                                      S, 0, ws.ptr, wsb, None))
+    kx.sync()
+    want = kxo.mha(3000, H, 0, S, kvd, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    np.testing.assert_allclose(out.numpy(np.float32, (H, hs)), want, rtol=0, atol=2e-5)
+    assert L.kx_attn_workspace_reset(ws.ptr, 100, None) == -1
 
 
 def test_mha_decode_forced_rescale_and_no_workspace():
