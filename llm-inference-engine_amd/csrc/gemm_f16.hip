@@ -552,26 +552,28 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
 }
 
 // acc = part 0 + part 1 + ... in index order, every part (this workgroup's own too) read back from
-// its slab with device-scope loads; the loads of one row of blocks are all in flight together.
+// its slab with device-scope loads; the S loads of one 16 x 16 block are in flight together and
+// the unrolled loop lets the next blocks' loads go out under the sums.  Row blocks past the last
+// row (`live` blocks of 16 rows in this wave's tile) were never stored and are skipped.
 template <int S>
-__device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t rs, unsigned lane_off) {
+__device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t rs, unsigned lane_off,
+                                           int live) {
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
-    u32x4 v[S][4];
-#pragma unroll
-    for (int pp = 0; pp < S; ++pp)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        v[pp][ni] = __builtin_amdgcn_raw_buffer_load_b128(
-            rs, (unsigned)pp * 262144u + lane_off + (mi * 4 + ni) * 1024, 0, 16);
+    if (mi >= live) break;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      f32x4 t = {__uint_as_float(v[0][ni].x), __uint_as_float(v[0][ni].y), __uint_as_float(v[0][ni].z),
-                 __uint_as_float(v[0][ni].w)};
+      u32x4 v[S];
+#pragma unroll
+      for (int pp = 0; pp < S; ++pp)
+        v[pp] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (unsigned)pp * 262144u + lane_off + (mi * 4 + ni) * 1024, 0, 16);
+      f32x4 t = {__uint_as_float(v[0].x), __uint_as_float(v[0].y), __uint_as_float(v[0].z),
+                 __uint_as_float(v[0].w)};
 #pragma unroll
       for (int pp = 1; pp < S; ++pp) {
-        t[0] += __uint_as_float(v[pp][ni].x); t[1] += __uint_as_float(v[pp][ni].y);
-        t[2] += __uint_as_float(v[pp][ni].z); t[3] += __uint_as_float(v[pp][ni].w);
+        t[0] += __uint_as_float(v[pp].x); t[1] += __uint_as_float(v[pp].y);
+        t[2] += __uint_as_float(v[pp].z); t[3] += __uint_as_float(v[pp].w);
       }
       acc[mi][ni] = t;
     }
@@ -679,8 +681,11 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         a.slabs + (size_t)(wgid - a.full_tiles) * nsplit * 65536, 0, (unsigned)nsplit * 262144u, 0x00020000);
     const unsigned mine = (unsigned)part * 262144u + (unsigned)(wave * 32 * 1024 + lane * 16);
+    // 16-row blocks of this wave's tile that hold real rows (a short prompt fills few of them)
+    const int live = min(8, max(0, (a.T - (t0 + wr * 128) + 15) / 16));
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < 8; ++mi) {
+      if (mi >= live) break;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         u32x4 v;
@@ -688,6 +693,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
         v.z = __float_as_uint(acc[mi][ni][2]); v.w = __float_as_uint(acc[mi][ni][3]);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + (mi * 4 + ni) * 1024, 0, 16);
       }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // also: every wave is past its last read of the K-tile buffers
     int* flag = reinterpret_cast<int*>(smem);
@@ -697,8 +703,12 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
     if (!last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: sc1 loads below
     const unsigned lane_off = (unsigned)(wave * 32 * 1024 + lane * 16);
-    if (nsplit == 2) gp_combine<2>(acc, rs, lane_off);
-    else gp_combine<4>(acc, rs, lane_off);
+    switch (nsplit) {
+      case 2: gp_combine<2>(acc, rs, lane_off, live); break;
+      case 4: gp_combine<4>(acc, rs, lane_off, live); break;
+      case 8: gp_combine<8>(acc, rs, lane_off, live); break;
+      default: gp_combine<16>(acc, rs, lane_off, live); break;
+    }
   }
   if (a.wide_rows) {
     __syncthreads();  // every wave's last tile reads and LDS-DMA landings are over: LDS is free
@@ -718,20 +728,22 @@ constexpr size_t kSplitTicketBytes = 4096;
 constexpr size_t kSplitSlabBytes = 256 * 256 * 4;
 constexpr int kPipeCUs = 256;
 
-// How many parts (1, 2 or 4) the reduction of the tiles of the last, partial round is cut into.
-// Model, in microseconds (fitted on 8B-sized matrices at 512..4096 rows): a K-tile step takes
-// ~1.45; a round of R tiles cut S ways costs ceil(R S / 256) rounds of nt / S steps, plus the
-// slabs' way through memory -- every part writes 256 KiB and the last arriver reads them all
-// back, ~0.16 per slab with the whole chip doing it at once.
-static int pipe_split_choice(int tiles, int nt, size_t split_ws_bytes) {
+// How many parts (1, 2, 4, 8 or 16) the reduction of the tiles of the last, partial round is cut
+// into.  Model, in microseconds (fitted on 8B-sized matrices at 64..4096 rows): a K-tile step takes
+// ~1.45, a part costs ~4 on top of its steps (pipeline fill, epilogue); a round of R tiles cut S
+// ways takes ceil(R S / 256) rounds of nt / S steps, plus the slabs' way through memory -- every
+// part writes its live rows (256 KiB for a full tile) and the last arriver reads them all back,
+// ~0.16 per full slab with the whole chip doing it at once.
+static int pipe_split_choice(int tiles, int nt, int T, size_t split_ws_bytes) {
   const int R = tiles % kPipeCUs;
   if (R == 0 || split_ws_bytes <= kSplitTicketBytes) return 1;
   const size_t slabs_fit = (split_ws_bytes - kSplitTicketBytes) / kSplitSlabBytes;
+  const double live = T >= 256 ? 1.0 : (double)((T + 15) / 16 * 16) / 256.0;  // share of a slab in use
   int best = 1;
-  double best_cost = 1.45 * nt;
-  for (int S = 2; S <= 4; S *= 2) {
+  double best_cost = 1.45 * nt + 4.0;
+  for (int S = 2; S <= 16; S *= 2) {
     if (nt < 8 * S || (size_t)R * S > slabs_fit || R > (int)(kSplitTicketBytes / 4)) continue;
-    const double cost = (double)((R * S + kPipeCUs - 1) / kPipeCUs) * 1.45 * nt / S + 0.16 * R * S + 3.0;
+    const double cost = (double)((R * S + kPipeCUs - 1) / kPipeCUs) * (1.45 * nt / S + 4.0) + 0.16 * live * R * S;
     if (cost < 0.95 * best_cost) {
       best_cost = cost;
       best = S;
@@ -750,11 +762,11 @@ static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_b
   if (opted_in.first())
     KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
-  int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, split_ws_bytes) : 1;
-  if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2 or 4
+  int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, a.T, split_ws_bytes) : 1;
+  if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
     const int want = atoi(e);
     const size_t need = kSplitTicketBytes + (size_t)(tiles % kPipeCUs) * want * kSplitSlabBytes;
-    if (want == 1 || ((want == 2 || want == 4) && split_ws && split_ws_bytes >= need &&
+    if (want == 1 || ((want == 2 || want == 4 || want == 8 || want == 16) && split_ws && split_ws_bytes >= need &&
                       a.M / GF_BK >= 2 * want && tiles % kPipeCUs && tiles % kPipeCUs <= 1024))
       split = want;
   }

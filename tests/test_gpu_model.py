@@ -420,6 +420,36 @@ def test_kept_fp16_weight_images_give_the_same_prompt_results():
     assert np.abs(outs[1][1] - outs[1][4]).max() > 0
 
 
+def test_short_prompts_use_the_kept_weight_images():
+    # once every matrix keeps its fp16 image, prompts from 32 rows up run the fp16 GEMMs (with cut
+    # reductions: few tiles, many idle CUs) instead of the int8 single-pass kernel; same tolerance
+    # against one fp32 decode step per row as the long-prompt form
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    rng = np.random.default_rng(9)
+    m = host.Model(seq_len=640, group_size=GS, prefill_weight_cache=1, **shape)
+    m.init_synthetic(31)
+    ref = host.Model(seq_len=640, group_size=GS, **shape)
+    ref.init_synthetic(31)
+    m.prefill(rng.integers(0, 1000, 520).astype(np.int32))      # leaves the images behind
+    for n in (33, 100, 300):
+        p = rng.integers(0, 1000, n).astype(np.int32)
+        got = m.prefill(p)
+        want = ref.prefill(p, exact=True)
+        assert np.abs(got - want).max() <= 4e-3 * np.abs(want).max(), n
+        assert int(np.argmax(got)) == int(np.argmax(want)) or np.sort(want)[-1] - np.sort(want)[-2] < 1e-2
+        for layer in range(2):
+            k, v = m.read_kv(layer, n)
+            kr, vr = ref.read_kv(layer, n)
+            assert np.abs(k - kr).max() <= 4e-3 * np.abs(kr).max()
+            assert np.abs(v - vr).max() <= 4e-3 * np.abs(vr).max()
+        assert m.state()[1] == n
+        m.decode(3, use_graph=False)
+        ref.decode(3, use_graph=False)
+    m.close()
+    ref.close()
+
+
 def test_tp_shards_are_slices_of_the_unsharded_weights():
     # column-parallel rows / row-parallel columns as the shard plan says, for synthetic weights
     shape = dict(dim=512, hidden_dim=1024, layer_num=1, head_num=8, kv_head_num=2, vocab_size=256,

@@ -1,6 +1,7 @@
 """Runs only the prompt pass of a model (random-init weights) a few times and prints tok/s; the
 command to put behind rocprofv3 --kernel-trace --stats for a per-kernel view of the prompt pass.
-usage: bench_prefill_model.py [model] [tokens] [passes]"""
+usage: bench_prefill_model.py [model] [tokens] [passes] [warm_tokens]
+warm_tokens > 0: a prompt of that many rows goes first (512+ rows leave the fp16 weight images behind)."""
 import os
 import sys
 import time
@@ -17,9 +18,12 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     shape = host.MODEL_SHAPES[name]
-    model = host.Model(seq_len=(n + 127) // 64 * 64, group_size=64, **shape)
+    warm = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    model = host.Model(seq_len=(max(n, warm) + 127) // 64 * 64, group_size=64, **shape)
     model.init_synthetic(1234)
     prompt = np.random.default_rng(42).integers(0, shape["vocab_size"], n).astype(np.int32)
+    if warm:
+        model.prefill(np.random.default_rng(43).integers(0, shape["vocab_size"], warm).astype(np.int32))
     model.prefill(prompt)
     model.sync()
     for _ in range(passes):
