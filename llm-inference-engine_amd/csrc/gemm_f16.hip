@@ -551,8 +551,9 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
   }
 }
 
-// acc = part 0 + part 1 + ... in index order, every part (this workgroup's own too) read back from
-// its slab with device-scope loads; the S loads of one 16 x 16 block are in flight together and
+// acc = part 0 + part 1 + ... in index order (three parts or more: the sum must not depend on which
+// part arrives last), every part (this workgroup's own too) read back from its slab with
+// device-scope loads; the S loads of one 16 x 16 block are in flight together and
 // the unrolled loop lets the next blocks' loads go out under the sums.  Row blocks past the last
 // row (`live` blocks of 16 rows in this wave's tile) were never stored and are skipped.
 template <int S>
@@ -704,7 +705,19 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: sc1 loads below
     const unsigned lane_off = (unsigned)(wave * 32 * 1024 + lane * 16);
     switch (nsplit) {
-      case 2: gp_combine<2>(acc, rs, lane_off, live); break;
+      case 2:  // a + b = b + a: the other part's slab onto this part's registers
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          if (mi >= live) break;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                rs, (unsigned)(part ^ 1) * 262144u + lane_off + (mi * 4 + ni) * 1024, 0, 16);
+            acc[mi][ni][0] += __uint_as_float(v.x); acc[mi][ni][1] += __uint_as_float(v.y);
+            acc[mi][ni][2] += __uint_as_float(v.z); acc[mi][ni][3] += __uint_as_float(v.w);
+          }
+        }
+        break;
       case 4: gp_combine<4>(acc, rs, lane_off, live); break;
       case 8: gp_combine<8>(acc, rs, lane_off, live); break;
       default: gp_combine<16>(acc, rs, lane_off, live); break;
