@@ -61,10 +61,10 @@ __global__ __launch_bounds__(256) void kv_to_f16_kernel(const KVT* __restrict__ 
     const f32x4 kv = fa_load4(kc + src);
     const f32x4 vv = fa_load4(vc + src);
     f16x4 h;
-    h[0] = (_Float16)kv.x; h[1] = (_Float16)kv.y; h[2] = (_Float16)kv.z; h[3] = (_Float16)kv.w;
+    h[0] = sat_f16(kv.x); h[1] = sat_f16(kv.y); h[2] = sat_f16(kv.z); h[3] = sat_f16(kv.w);
     *reinterpret_cast<f16x4*>(k16 + ((size_t)kvh * s_pad + key0 + key) * HS + d4) = h;
     _Float16* row = vt + key * VROW + d4;
-    row[0] = (_Float16)vv.x; row[1] = (_Float16)vv.y; row[2] = (_Float16)vv.z; row[3] = (_Float16)vv.w;
+    row[0] = sat_f16(vv.x); row[1] = sat_f16(vv.y); row[2] = sat_f16(vv.z); row[3] = sat_f16(vv.w);
   }
   __syncthreads();
   for (int item = tid; item < HS * (FA_KV / 8); item += 256) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
                    o[dt][4 * g + 3] * inv};
         if (a.out16) {
           f16x4 h;
-          h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+          h[0] = sat_f16(v.x); h[1] = sat_f16(v.y); h[2] = sat_f16(v.z); h[3] = sat_f16(v.w);
           *reinterpret_cast<f16x4*>(a.out16 + off + 32 * dt + 8 * g) = h;
         } else {
           *reinterpret_cast<f32x4*>(a.out + off + 32 * dt + 8 * g) = v;

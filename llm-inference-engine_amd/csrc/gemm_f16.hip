@@ -58,7 +58,7 @@ __global__ void f32_to_f16_rows_kernel(const float* __restrict__ x, int64_t ldx,
     const int c = (int)(i - t * m4) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * ldx + c);
     f16x4 h;
-    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    h[0] = sat_f16(v.x); h[1] = sat_f16(v.y); h[2] = sat_f16(v.z); h[3] = sat_f16(v.w);
     *reinterpret_cast<f16x4*>(y + t * ldy + c) = h;
   }
 }
@@ -132,7 +132,7 @@ __device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f3
           const int t = trow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (t < a.T) {
             const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 1][r] * fu;
-            a.h16[(size_t)t * half_k + j] = (_Float16)(g * (1.0f / (1.0f + expf(-g))) * u);
+            a.h16[(size_t)t * half_k + j] = sat_f16(g * (1.0f / (1.0f + expf(-g))) * u);
           }
         }
     }
@@ -192,7 +192,7 @@ __device__ __forceinline__ void gemm_f16_epilogue16(const GemmF16Args& a, const 
           const int t = trow0 + mi * 16 + frow4 + r;
           if (t < a.T) {
             const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 2][r] * fu;
-            a.h16[(size_t)t * half_k + j] = (_Float16)(g * (1.0f / (1.0f + expf(-g))) * u);
+            a.h16[(size_t)t * half_k + j] = sat_f16(g * (1.0f / (1.0f + expf(-g))) * u);
           }
         }
     }
@@ -456,7 +456,7 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
           const int row = wr * 128 + mi * 16 + 4 * g + r;
           const float gv = acc[mi][ni][r] * fg, uv = acc[mi][ni + 2][r] * fu;
           wb[row * 128 + ((((unit >> 3) ^ (row & 15)) << 3) | (unit & 7))] =
-              (_Float16)(gv * (1.0f / (1.0f + expf(-gv))) * uv);
+              sat_f16(gv * (1.0f / (1.0f + expf(-gv))) * uv);
         }
     }
     __syncthreads();

@@ -5,6 +5,12 @@
 
 #include "../../include/kx_hip.h"
 
+// fp32 -> fp16 with saturation: a value past the fp16 range becomes +-65504 instead of an
+// infinity that would turn into NaN in the next product (one v_med3_f32 ahead of the conversion).
+__device__ __forceinline__ _Float16 sat_f16(float x) {
+  return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+}
+
 // A kernel's raised dynamic-LDS limit (hipFuncSetAttribute) holds for the device that was current
 // when it was set: one flag per device and call site.  first() is true once per device.
 struct OncePerDevice {

@@ -34,8 +34,8 @@ __global__ void rmsnorm_f16out_kernel(const float* __restrict__ in, const float*
   for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
     const f32x4 v = x4[i], w = w4[i];
     f16x4 h;
-    h[0] = (_Float16)(w.x * (rs * v.x)); h[1] = (_Float16)(w.y * (rs * v.y));
-    h[2] = (_Float16)(w.z * (rs * v.z)); h[3] = (_Float16)(w.w * (rs * v.w));
+    h[0] = sat_f16(w.x * (rs * v.x)); h[1] = sat_f16(w.y * (rs * v.y));
+    h[2] = sat_f16(w.z * (rs * v.z)); h[3] = sat_f16(w.w * (rs * v.w));
     o4[i] = h;
   }
 }

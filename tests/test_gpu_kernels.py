@@ -704,6 +704,21 @@ def test_gemm_w8_f16_qkv_with_bias_and_rope_in_the_epilogue(hs, variant, T, pos0
                                         None) == -2
 
 
+def test_fp16_activations_saturate_instead_of_overflowing():
+    # silu(g) * u and the normalised rows leave as fp16: a value past 65504 must stay finite
+    T, K, M = 256, 128, 64
+    w = np.full((K, M), 127, np.int8)
+    s = np.ones(K * M // GS, np.float32)
+    X16 = np.ones((T, M), np.float16)
+    h = kx.gemm_w8_f16act(X16, w, s, GS, swiglu=True)       # gate = up = 8128 -> 6.6e7
+    assert np.all(h == np.float16(65504.0))
+    x = np.full((4, 128), 3.0, np.float32)
+    out = kx.rmsnorm_f16out(x, np.full(128, 1e6, np.float32))
+    assert np.all(out == np.float16(65504.0))
+    out = kx.rmsnorm_f16out(-x, np.full(128, 1e6, np.float32))
+    assert np.all(out == np.float16(-65504.0))
+
+
 def test_gemm_w8_f16_activations_preconditions():
     L = kx.lib()
     T, K, M = 256, 128, 128
