@@ -499,8 +499,17 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
     tall_x = blocks1 <= 256 * fit;
     if (tall_x) threads = 1024;
   }
-  // rows a wave keeps in flight together; the gate/up form already doubles the loads
-  const int R = tall_x ? 1 : mode == GEMV_GATE_UP ? 1 : (a.chunks <= 2 ? 4 : 2);
+  // Few rows in all (fewer than 8 waves per CU at the usual rows per wave; Llama-3.2-1B: Wo 2048 x 2048,
+  // W2 2048 x 8192): one row per wave as well, in smaller workgroups -- twice to four times the
+  // waves hide each other's latency (3.9 -> 3.2 us and 6.8 -> 5.5 us on those two).
+  if (mode == GEMV_PLAIN && !tall_x && out_rows / (a.chunks <= 2 ? 4 : 2) < 2048) {
+    tall_x = true;
+    threads = a.chunks >= 2 ? 512 : 256;
+  }
+  // rows a wave keeps in flight together; the gate/up form already doubles the loads.  The fused
+  // QKV form needs both rows of a rotation pair in one wave and is best at exactly two (3072 x 2048:
+  // 5.6 us with four rows per wave, 4.3 us with two).
+  const int R = tall_x ? 1 : mode == GEMV_GATE_UP ? 1 : mode == GEMV_QKV_ROPE ? 2 : (a.chunks <= 2 ? 4 : 2);
   const int per_iter = (threads / 64) * R;
   // aim for ~4 workgroups per CU on big matrices, one pass on small ones
   const int target_blocks = 256 * 4;
@@ -520,8 +529,7 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
                            : launch<1, 4, GEMV_GATE_UP>(a, threads, s);
     case GEMV_QKV_ROPE:
       if (a.K % 2 || a.k0 % 2 || a.k1 % 2 || a.head_size % 2) return KX_EINVAL;
-      return a.chunks <= 2 ? launch<4, 2, GEMV_QKV_ROPE>(a, threads, s)
-                           : launch<2, 2, GEMV_QKV_ROPE>(a, threads, s);
+      return launch<2, 2, GEMV_QKV_ROPE>(a, threads, s);
     default:
       if (tall_x) return launch<1, 4, GEMV_PLAIN>(a, threads, s);
       return a.chunks <= 2 ? launch<4, 2, GEMV_PLAIN>(a, threads, s)
