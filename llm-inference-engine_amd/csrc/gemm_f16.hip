@@ -370,6 +370,7 @@ struct GemmPipeCtx {
   int abase, bbase;           // byte offset of this lane's fragment row in the A / B region
   int coff[2];                // swizzled 16-byte chunk offset per k-step of 32
   int nt;
+  bool live_lo, live_hi;      // rows 0-63 / 64-127 of this wave's tile hold real rows (short prompts)
 };
 
 template <int PIECE, int BUFSEL>
@@ -395,7 +396,7 @@ __device__ __forceinline__ void gp_read16(const char* smem, int base, const int 
 // One phase: issue a piece, wait until all but the newest four pieces have landed, barrier, the
 // quadrant's 16 MFMAs (row blocks MI0 .. MI0 + 3 x column blocks NI0, NI0 + 1), barrier.  The
 // priority pair keeps the compiler from moving MFMAs across the barriers in among the loads.
-#define GP_PHASE(PIECE, BUFSEL, TILE, MI0, NI0, BREG)                                                   \
+#define GP_PHASE(PIECE, BUFSEL, TILE, MI0, NI0, BREG, LIVE)                                             \
   gp_issue<PIECE, BUFSEL>(smem, c, TILE);                                                               \
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -403,11 +404,13 @@ __device__ __forceinline__ void gp_read16(const char* smem, int base, const int 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                                        \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
-    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                       \
-      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
-        acc[MI0 + m][NI0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][kk], BREG[n][kk],          \
-                                                                       acc[MI0 + m][NI0 + n], 0, 0, 0); \
+  if (LIVE) {                                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                     \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                   \
+          acc[MI0 + m][NI0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][kk], BREG[n][kk],        \
+                                                                         acc[MI0 + m][NI0 + n], 0, 0, 0); \
+  }                                                                                                     \
   __builtin_amdgcn_s_setprio(0);                                                                        \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_barrier();                                                                         \
@@ -415,21 +418,25 @@ __device__ __forceinline__ void gp_read16(const char* smem, int base, const int 
 
 // One K-tile (four phases).  PAR = t & 1 selects the buffer; bq0 holds columns 0-31 of this tile on
 // entry, bq1 receives columns 32-63 in phase 1 and columns 0-31 of tile t + 1 in phase 3.
-template <int PAR>
+// SHORT (prompts of at most 128 rows: one row tile, most of it padding): waves whose 64-row
+// halves hold no real row skip the fragment reads and the MFMAs of those halves -- the matrix pipe
+// stops setting the pace of a K-tile step, the weight stream does.
+template <int PAR, bool SHORT>
 __device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t, f32x4 (&acc)[8][4],
                                         f16x8 (&af)[4][2], f16x8 (&bq0)[2][2], f16x8 (&bq1)[2][2]) {
+  const bool lo = SHORT ? c.live_lo : true, hi = SHORT ? c.live_hi : true;
   // phase 0: rows 0-63 of the wave tile x columns 0-31
-  gp_read16<PAR, 0, 4>(smem, c.abase, c.coff, af);
-  GP_PHASE(2, PAR ^ 1, t + 1, 0, 0, bq0);
+  if (lo) gp_read16<PAR, 0, 4>(smem, c.abase, c.coff, af);
+  GP_PHASE(2, PAR ^ 1, t + 1, 0, 0, bq0, lo);
   // phase 1: rows 0-63 x columns 32-63
   gp_read16<PAR, 2, 2>(smem, c.bbase, c.coff, bq1);
-  GP_PHASE(3, PAR ^ 1, t + 1, 0, 2, bq1);
+  GP_PHASE(3, PAR ^ 1, t + 1, 0, 2, bq1, lo);
   // phase 2: rows 64-127 x columns 32-63
-  gp_read16<PAR, 4, 4>(smem, c.abase, c.coff, af);
-  GP_PHASE(0, PAR, t + 2, 4, 2, bq1);
+  if (hi) gp_read16<PAR, 4, 4>(smem, c.abase, c.coff, af);
+  GP_PHASE(0, PAR, t + 2, 4, 2, bq1, hi);
   // phase 3: rows 64-127 x columns 0-31; columns 0-31 of the next tile replace columns 32-63
   gp_read16<PAR ^ 1, 0, 2>(smem, c.bbase, c.coff, bq1);
-  GP_PHASE(1, PAR, t + 2, 4, 0, bq0);
+  GP_PHASE(1, PAR, t + 2, 4, 0, bq0, hi);
 }
 
 // Epilogue of the pipelined kernel through LDS (free once the main loop is over): a wave turns
@@ -590,7 +597,7 @@ __device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_r
   }
 }
 
-template <bool SWIGLU, bool ROPE = false>
+template <bool SWIGLU, bool ROPE = false, bool SHORT = false>
 __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -643,6 +650,8 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
         c.dst[piece][j] = (is_a ? 0 : GP_BOFF) + row * 128;
       }
     }
+    c.live_lo = t0 + wr * 128 < a.T;
+    c.live_hi = t0 + wr * 128 + 64 < a.T;
     const int frow = lane & 15, kq = lane >> 4, key = (frow >> 1) & 7;
     c.abase = (wr * 128 + frow) * 128;
     c.bbase = GP_BOFF + (wc * 64 + frow) * 128;
@@ -677,8 +686,8 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   __builtin_amdgcn_s_barrier();
 
   for (int t = 0; t < c.nt; t += 2) {
-    gp_tile<0>(smem, c, t, acc, af, bx, by);
-    if (t + 1 < c.nt) gp_tile<1>(smem, c, t + 1, acc, af, by, bx);
+    gp_tile<0, SHORT>(smem, c, t, acc, af, bx, by);
+    if (t + 1 < c.nt) gp_tile<1, SHORT>(smem, c, t + 1, acc, af, by, bx);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads target this LDS
@@ -743,6 +752,9 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_qkv_rope_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false, true>(a); }
+__global__ __launch_bounds__(512, 1) void gemm_f16_pipe_short_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false, false, true>(a); }
+__global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_short_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true, false, true>(a); }
+__global__ __launch_bounds__(512, 1) void gemm_f16_pipe_qkv_rope_short_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false, true, true>(a); }
 
 // Split workspace: kSplitTicketBytes of arrival tickets (one per tile of the last, partial round),
 // then 256 KiB slabs.
@@ -893,8 +905,15 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   int choice = 0;
   if (const char* e = getenv("KX_GEMM_F16_KERNEL")) choice = atoi(e);  // a few ns; read per call so tests can switch
   if (choice != 1 && choice != 3) choice = M >= 512 ? 3 : 1;
+  // at most 128 rows: the variant that skips the matrix work of all-padding wave halves
+  const bool short_rows = T <= 128 && !getenv("KX_GEMM_NO_SHORT");
   if (qkv_form)  // only the pipelined kernel has this epilogue; the caller checked the shape
-    return launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_kernel>(a, split_ws, split_ws_bytes, s, true);
+    return short_rows
+               ? launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_short_kernel>(a, split_ws, split_ws_bytes, s, true)
+               : launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_kernel>(a, split_ws, split_ws_bytes, s, true);
+  if (choice == 3 && short_rows)
+    return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_short_kernel>(a, split_ws, split_ws_bytes, s)
+                  : launch_gemm_f16_pipe<gemm_f16_pipe_short_kernel>(a, split_ws, split_ws_bytes, s);
   if (choice == 3)
     return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, split_ws, split_ws_bytes, s)
                   : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, split_ws, split_ws_bytes, s);
