@@ -167,7 +167,6 @@ class LlamaModel {
                              int32_t col0, int32_t cols);
   static constexpr int32_t kPrefillChunk = 4096;  // prompt rows per batched pass
   base::Status reserve_weight_images();
-  bool images_all_ready() const;  // every layer matrix holds a finished fp16 image
   void drop_weight_images(bool free_memory);
   int weight_images_ = 0;  // 0 not decided yet, 1 in use, -1 not available
   base::Status prefill_sequential(const int32_t* tokens, int32_t n, int32_t pos0, float* logits_host);

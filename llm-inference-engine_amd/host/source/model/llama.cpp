@@ -250,14 +250,6 @@ base::Status LlamaModel::reserve_weight_images() {
   return base::error::Success();
 }
 
-bool LlamaModel::images_all_ready() const {
-  if (weight_images_ != 1) return false;
-  for (const auto& l : layers_)
-    for (const Linear* m : {&l.qkv, &l.wo, &l.w13, &l.w2})
-      if (!m->w16 || !m->w16_ready) return false;
-  return true;
-}
-
 void LlamaModel::drop_weight_images(bool free_memory) {
   for (auto& l : layers_)
     for (Linear* m : {&l.qkv, &l.wo, &l.w13, &l.w2}) {
@@ -1030,13 +1022,16 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     KX_RET(kx_embedding_f32(history_dev_ + p0, rows, emb_, dim, c.vocab_size, X, st));
     // per-layer GEMM time of the two forms on the 8B matrices ties at 512..640 rows; the fp16 form
     // also saves the separate SwiGLU pass
-    // ... while the fp16 weight images have to be made per pass.  Once every matrix keeps its
-    // image the fp16 form costs no conversion and wins from 32 rows up (Llama-3-8B, 32 / 128 / 384
-    // rows: 9.1 / 10.4 / 10.8 ms against 16.9 / 18.5 / 22.4 ms for the int8 single-pass kernel).
-    int32_t f16_min_rows = images_all_ready() ? 32 : 512;
+    // ... while the fp16 weight images have to be made per pass.  A model that keeps its images
+    // (prefill_weight_cache, decided here at the first prompt of 32+ rows) pays the conversion once
+    // per matrix, and from then on the fp16 form wins from 32 rows up (Llama-3-8B, 32 / 128 / 384
+    // rows: 6.2 / 9.1 / 11.7 ms against 16.9 / 18.4 / 22.4 ms for the int8 single-pass kernel).
+    // Which form a prompt takes depends on its length and on that one decision only, never on
+    // which prompts came before it.
+    if (f16_ok && rows >= 32) ST_RET(reserve_weight_images());
+    int32_t f16_min_rows = weight_images_ == 1 ? 32 : 512;
     if (const char* e = getenv("KX_PREFILL_F16_MIN_ROWS")) f16_min_rows = atoi(e);  // A/B runs
     const bool f16_chunk = f16_ok && rows >= f16_min_rows;
-    if (f16_chunk) ST_RET(reserve_weight_images());
     for (int32_t l = 0; l < c.layer_num; ++l) {
       LayerWeights& lw = layers_[l];
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);

@@ -421,9 +421,10 @@ def test_kept_fp16_weight_images_give_the_same_prompt_results():
 
 
 def test_short_prompts_use_the_kept_weight_images():
-    # once every matrix keeps its fp16 image, prompts from 32 rows up run the fp16 GEMMs (with cut
-    # reductions: few tiles, many idle CUs) instead of the int8 single-pass kernel; same tolerance
-    # against one fp32 decode step per row as the long-prompt form
+    # a model that keeps fp16 images of its weights runs prompts from 32 rows up on the fp16 GEMMs
+    # (with cut reductions: few tiles, many idle CUs) instead of the int8 single-pass kernel, whether
+    # or not a long prompt came first; same tolerance against one fp32 decode step per row as the
+    # long-prompt form
     shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
                  rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
     rng = np.random.default_rng(9)
@@ -431,7 +432,13 @@ def test_short_prompts_use_the_kept_weight_images():
     m.init_synthetic(31)
     ref = host.Model(seq_len=640, group_size=GS, **shape)
     ref.init_synthetic(31)
-    m.prefill(rng.integers(0, 1000, 520).astype(np.int32))      # leaves the images behind
+    fresh = host.Model(seq_len=640, group_size=GS, prefill_weight_cache=1, **shape)
+    fresh.init_synthetic(31)
+    p0 = rng.integers(0, 1000, 100).astype(np.int32)
+    first = fresh.prefill(p0)                                    # makes the images on the way
+    m.prefill(rng.integers(0, 1000, 520).astype(np.int32))      # images made by a long prompt
+    np.testing.assert_array_equal(first, m.prefill(p0))         # same form either way: same bits
+    fresh.close()
     for n in (33, 100, 300):
         p = rng.integers(0, 1000, n).astype(np.int32)
         got = m.prefill(p)
