@@ -1,0 +1,454 @@
+// W8A16 group-quant product for a FEW activation rows (2..64) on gfx950:
+//   Y[t][p] = sum_i X[t][i] * scales[(p*M+i)/64] * (float)w[p*M+i],   t < T <= 64.
+//
+// The reference has no batched matmul (its prompt phase feeds one token per launch,
+// demo/main.cpp:18-41; cuda/matmul_kernel.cu:89-134 ignore a second input dim).  With so few rows
+// the product is bound by the int8 weight stream, exactly like the decode GEMV, and the tiled
+// GEMMs (128- or 256-row tiles) leave most of the chip idle: a 32-row prompt on 4096 x 4096 is 32
+// of their tiles.  This kernel streams the weights once and multiplies them with all T rows on
+// the matrix cores (v_mfma_f32_16x16x32_f16; int8 is exact in fp16).
+//
+// Work split
+//   - a workgroup of five waves owns 128 weight rows and a slice of the reduction, walked in
+//     units of 128 elements (two quant groups).  Waves 0-3 own 32 rows each (two blocks of 16);
+//     wave 4 only brings in the activation rows.
+//   - everything arrives by LDS-DMA (global_load_lds, 16 bytes per lane), so loads in flight hold
+//     no registers and are waited for with hand-counted vmcnt.  A compute wave keeps a private
+//     ring of five unit slots (4 KiB of weights + the rows' scales each) and requests unit u + 4
+//     before it multiplies unit u: 12-16 KiB per wave in flight.  The activation units (T rows x
+//     128 halves) are shared, in three or four buffers; wave 4 requests them two or three units
+//     ahead and waits for them on its own counter, so that wait never drains the compute waves'
+//     weight prefetch (loads complete in order within a wave).
+//   - one DMA instruction covers 8 rows x 128 contiguous bytes (16 rows x 64 bytes, the
+//     operand layout itself, reads a quarter slower from HBM).  Inside LDS a row's eight 16-byte
+//     pieces are stored XOR-ed with a per-row key chosen so that the fragment reads
+//     (ds_read_b128, lane = row + 16 * piece pair) touch every bank once.
+//   - int8 -> fp16 without conversions: v_perm_b32 drops each (byte ^ 0x80) into the mantissa of
+//     0x6400 (= 1024 + byte + 128, exact), one v_pk_add_f16 takes the 1152 off again.
+//   - numerics as the tiled int8 kernel: activations are fp16, every group's 64 products are
+//     summed in fp32 by the matrix core, times the group's fp32 scale, added to an fp32 total.
+//
+// Narrow matrices cut the reduction S = 2, 4, 8 or 16 ways over workgroups: each part writes its
+// fp32 partial tile to a slab with write-through stores, takes an arrival ticket (which wraps back
+// to zero), and the last arriver of a tile adds the parts in index order with device-scope loads
+// and writes the rows -- the same sum whichever part arrives last.
+#include "kx_common.hpp"
+
+namespace kx {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+constexpr int FR_BN = 128;     // weight rows per workgroup
+constexpr int FR_KU = 128;     // reduction elements per unit
+constexpr int FR_RING = 5;     // weight unit slots per compute wave
+constexpr int FR_AHEAD = FR_RING - 1;
+constexpr int FR_SLOT = 5120;  // 4 x 1 KiB of weights + 1 KiB of scales
+constexpr int FR_NW = 5;       // DMA instructions per weight unit and wave
+constexpr size_t kRowsTicketBytes = 4096;
+constexpr size_t kRowsX16Bytes = 4u << 20;  // fp16 copy of fp32 activation rows (64 x 32768 at most)
+
+struct RowsArgs {
+  const _Float16* X;    // [T][ldx] fp16
+  const int8_t* w;      // [K][M]
+  const float* scales;  // [K][M/64]
+  const float* residual;
+  float* y0; float* y1; float* y2;  // weight-row ranges [0,k0) [k0,k1) [k1,K)
+  float* slabs;
+  unsigned* tickets;
+  int64_t ldx, ld0, ld1, ld2, ldr;
+  int32_t k0, k1;
+  int32_t T, M, K;
+  int32_t nsplit;
+};
+
+// four int8 -> four fp16 (two packed pairs), exact
+__device__ __forceinline__ void cvt_w8x4(uint32_t d, uint32_t& lo, uint32_t& hi) {
+  const uint32_t x = d ^ 0x80808080u;
+  const f16x2 off = {(_Float16)1152.0f, (_Float16)1152.0f};
+  const f16x2 a = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, x, 0x04010400u)) - off;
+  const f16x2 b = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, x, 0x04030402u)) - off;
+  lo = __builtin_bit_cast(uint32_t, a);
+  hi = __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ f16x8 cvt_w8x8(uint32_t d0, uint32_t d1) {
+  uint32_t a, b, c, d;
+  cvt_w8x4(d0, a, b);
+  cvt_w8x4(d1, c, d);
+  const u32x4 r = {a, b, c, d};
+  return __builtin_bit_cast(f16x8, r);
+}
+
+// waits until at most `units` weight units (FR_NW instructions each) are still in flight
+__device__ __forceinline__ void wait_units(int units) {
+  switch (units) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+  }
+}
+static_assert(FR_NW == 5 && FR_AHEAD == 4, "wait_units spells these counts out");
+
+template <int S, int TB>
+__device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TB], __amdgpu_buffer_rsrc_t rs, unsigned lane_off) {
+  constexpr unsigned PB = TB * 8192u;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      u32x4 v[S];
+#pragma unroll
+      for (int p = 0; p < S; ++p)
+        v[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)p * PB + lane_off + (rb * TB + tb) * 1024, 0, 16);
+      f32x4 t = {__uint_as_float(v[0].x), __uint_as_float(v[0].y), __uint_as_float(v[0].z),
+                 __uint_as_float(v[0].w)};
+#pragma unroll
+      for (int p = 1; p < S; ++p) {
+        t[0] += __uint_as_float(v[p].x); t[1] += __uint_as_float(v[p].y);
+        t[2] += __uint_as_float(v[p].z); t[3] += __uint_as_float(v[p].w);
+      }
+      acc[rb][tb] = t;
+    }
+}
+
+// activation unit buffers: as many as LDS has room for beside the weight rings
+template <int TB>
+constexpr int rows_xbufs() { return TB == 4 ? 3 : 4; }
+// LDS: [activation unit buffers: TB x 4 KiB each][weight rings: 4 waves x FR_RING x FR_SLOT]
+template <int TB>
+constexpr int rows_lds_bytes() { return rows_xbufs<TB>() * TB * 4096 + 4 * FR_RING * FR_SLOT; }
+
+template <int TB>
+__global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int XBUF = TB * 4096;  // one activation unit: 2 groups x TB token blocks x 2 halves x 1 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsplit = a.nsplit;
+  const int part = blockIdx.x % nsplit, tile = blockIdx.x / nsplit;
+  const int n0 = tile * FR_BN;
+  // this part's units [u0, u0 + un)
+  int u0, un;
+  {
+    const int nu = a.M / FR_KU, base = nu / nsplit, rem = nu % nsplit;
+    u0 = part * base + min(part, rem);
+    un = base + (part < rem ? 1 : 0);
+  }
+  constexpr int NXB = rows_xbufs<TB>();
+  char* const xbuf = smem;
+  char* const ring = smem + NXB * XBUF + (wave & 3) * (FR_RING * FR_SLOT);
+
+  f32x4 acc[2][TB];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) acc[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave == 4) {
+    // ---- activation rows: one instruction = 8 tokens x 128 bytes (one quant group) ----
+    // lane (r8, s) = (lane >> 3, lane & 7) fetches piece s ^ key of its token, key from the
+    // token's index inside its block of 16 with bits 0 and 1 of (index >> 1) exchanged
+    unsigned xoff[TB][2];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r8 = lane >> 3, x = h * 4 + (r8 >> 1);
+        const int key = ((x & 1) << 1) | ((x >> 1) & 1) | (x & 4);
+        const unsigned row = (unsigned)min(tb * 16 + h * 8 + r8, a.T - 1);
+        xoff[tb][h] = (row * (unsigned)a.ldx + (unsigned)u0 * FR_KU) * 2u + (unsigned)(((lane & 7) ^ key) * 16);
+      }
+    const char* const xbase = reinterpret_cast<const char*>(a.X);
+    auto issue_x = [&](int u) {
+      char* dst = xbuf + (u % NXB) * XBUF;
+#pragma unroll
+      for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const uint32_t*>(xbase + (xoff[tb][h] + (unsigned)(u * FR_KU + gl * 64) * 2u)),
+                (lds_ptr_t)(dst + ((gl * TB + tb) * 2 + h) * 1024), 16, 0, 0);
+    };
+    // unit u + NXB - 1 is requested after the barrier that ends unit u - 1 (whose buffer it takes)
+    // and has NXB - 1 units' time to arrive: one unit ahead, every unit would take a whole trip
+    // to L2, and that trip, not the weight stream, would set the pace
+#pragma unroll
+    for (int u = 0; u < NXB - 1; ++u)
+      if (u < un) issue_x(u);
+    for (int u = 0; u < un; ++u) {
+      // unit u has landed when at most the younger ones (TB * 4 instructions each) are in flight
+      const int younger = min(NXB - 2, un - 1 - u);
+      if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TB * 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TB * 8) : "memory");
+      __builtin_amdgcn_s_barrier();  // unit u is in place; unit u - 1 has been multiplied by every wave
+      if (u + NXB - 1 < un) issue_x(u + NXB - 1);
+    }
+  } else {
+    // ---- weights: one instruction = 8 rows x 128 bytes (the whole unit of those rows) ----
+    // lane (r8, s) fetches piece s ^ key of its row, key = (row's index in its block of 16) >> 1
+    unsigned woff[2][2], soff;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r8 = lane >> 3, key = h * 4 + (r8 >> 1);
+        // rows past the end re-read the last row; their results are never stored
+        const unsigned n = (unsigned)min(n0 + wave * 32 + rb * 16 + h * 8 + r8, a.K - 1);
+        woff[rb][h] = n * (unsigned)a.M + (unsigned)u0 * FR_KU + (unsigned)(((lane & 7) ^ key) * 16);
+      }
+    {
+      const unsigned n = (unsigned)min(n0 + wave * 32 + (lane & 31), a.K - 1);
+      soff = n * (unsigned)(a.M / 64) * 4u;
+    }
+    const char* const wbase = reinterpret_cast<const char*>(a.w);
+    const char* const sbase = reinterpret_cast<const char*>(a.scales);
+    auto issue_w = [&](int u) {
+      char* dst = ring + (u % FR_RING) * FR_SLOT;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          __builtin_amdgcn_global_load_lds(
+              reinterpret_cast<const uint32_t*>(wbase + (woff[rb][h] + (unsigned)u * FR_KU)),
+              (lds_ptr_t)(dst + (rb * 2 + h) * 1024), 16, 0, 0);
+      // the 16 bytes of scales that hold this unit's two groups (four groups per 16 bytes)
+      __builtin_amdgcn_global_load_lds(
+          reinterpret_cast<const uint32_t*>(sbase + (soff + (unsigned)((u0 + u) >> 1) * 16u)),
+          (lds_ptr_t)(dst + 4096), 16, 0, 0);
+    };
+    // fragment addresses: lane (j, q) = (lane & 15, lane >> 4)
+    const int j = lane & 15, q = lane >> 4;
+    int rdw[2], rdx[2];
+    {
+      const int h = j >> 3, r8 = j & 7, keyw = j >> 1;
+      const int x = j >> 1, keyx = ((x & 1) << 1) | ((x >> 1) & 1) | (x & 4);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) rdw[g] = h * 1024 + (r8 * 8 + ((g * 4 + q) ^ keyw)) * 16;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) rdx[m] = h * 1024 + (r8 * 8 + ((q * 2 + m) ^ keyx)) * 16;
+    }
+
+#pragma unroll
+    for (int u = 0; u < FR_AHEAD; ++u)
+      if (u < un) issue_w(u);
+    for (int u = 0; u < un; ++u) {
+      if (u + FR_AHEAD < un) issue_w(u + FR_AHEAD);
+      wait_units(min(FR_AHEAD, un - 1 - u));
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* slot = ring + (u % FR_RING) * FR_SLOT;
+      const char* xb = xbuf + (u % NXB) * XBUF;
+      const int sel = ((u0 + u) & 1) * 2;
+      f32x4 sv[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) sv[rb] = *reinterpret_cast<const f32x4*>(slot + 4096 + (rb * 16 + j) * 16);
+#pragma unroll
+      for (int gl = 0; gl < 2; ++gl) {
+        f16x8 xa[TB][2];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            xa[tb][m] = *reinterpret_cast<const f16x8*>(xb + (gl * TB + tb) * 2048 + rdx[m]);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const u32x4 wv = *reinterpret_cast<const u32x4*>(slot + rb * 2048 + rdw[gl]);
+          const f16x8 w0 = cvt_w8x8(wv.x, wv.y);
+          const f16x8 w1 = cvt_w8x8(wv.z, wv.w);
+          const float sc = sel ? (gl ? sv[rb][3] : sv[rb][2]) : (gl ? sv[rb][1] : sv[rb][0]);
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) {
+            f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tb][0], w0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tb][1], w1, g, 0, 0, 0);
+            // Element by element on purpose (this file is built without SLP vectorisation): as
+            // v_pk_fma_f32 with the scale picked by op_sel from the upper half of a register pair,
+            // an earlier form of this kernel lost a group's update in lanes 48-63 of the lower
+            // result on the device (timing dependent).
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][tb][r] = __builtin_fmaf(g[r], sc, acc[rb][tb][r]);
+          }
+        }
+      }
+      // this wave's reads of the slot and of the activation unit are done before it requests
+      // anything into them again (the slot: next iteration; the unit: wave 4, after the barrier)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  const bool computes = wave < 4;
+  if (nsplit > 1) {
+    constexpr unsigned PB = TB * 8192u;  // one part's partial tile: [wave][row block][token block][lane] x 16 B
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.slabs) + (size_t)tile * nsplit * PB, 0, (unsigned)nsplit * PB, 0x00020000);
+    const unsigned lane_off = (unsigned)((wave & 3) * 2 * TB * 1024 + lane * 16);
+    if (computes) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+          u32x4 v;
+          v.x = __float_as_uint(acc[rb][tb][0]); v.y = __float_as_uint(acc[rb][tb][1]);
+          v.z = __float_as_uint(acc[rb][tb][2]); v.w = __float_as_uint(acc[rb][tb][3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)part * PB + lane_off + (rb * TB + tb) * 1024, 0, 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = atomicInc(a.tickets + tile, (unsigned)nsplit - 1u) == (unsigned)nsplit - 1u;
+    __syncthreads();
+    if (!*flag || !computes) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: device-scope loads below
+    switch (nsplit) {
+      case 2: rows_combine<2, TB>(acc, rs, lane_off); break;
+      case 4: rows_combine<4, TB>(acc, rs, lane_off); break;
+      case 8: rows_combine<8, TB>(acc, rs, lane_off); break;
+      default: rows_combine<16, TB>(acc, rs, lane_off); break;
+    }
+  }
+  if (!computes) return;
+
+  // ---- rows out: a lane holds tokens 4*(lane>>4)+r of weight row (lane&15) ----
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int n = n0 + wave * 32 + rb * 16 + (lane & 15);
+    if (n >= a.K) continue;
+    float* dst;
+    int64_t ld;
+    int col;
+    bool add_res = false;
+    if (n < a.k0) {
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+    } else if (n < a.k1) {
+      dst = a.y1; ld = a.ld1; col = n - a.k0;
+    } else {
+      dst = a.y2; ld = a.ld2; col = n - a.k1;
+    }
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = tb * 16 + 4 * (lane >> 4) + r;
+        if (t < a.T) {
+          float v = acc[rb][tb][r];
+          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
+          dst[(size_t)t * ld + col] = v;
+        }
+      }
+  }
+}
+
+// Parts per tile: one workgroup per CU is what LDS allows, so the reduction is cut until the
+// grid has about as many workgroups as the chip has CUs; never so finely that a part is left with
+// fewer units than the ring prefetches.
+static int rows_split_choice(int tiles, int nu, int TB, size_t slab_bytes) {
+  int S = 1;
+  while (S < 16 && tiles * S * 2 <= 256 && nu >= 4 * S && (size_t)tiles * (2 * S) * TB * 8192 <= slab_bytes)
+    S *= 2;
+  return S;
+}
+
+template <int TB>
+static int launch_rows(const RowsArgs& a, hipStream_t s) {
+  static OncePerDevice raised;
+  constexpr int lds = rows_lds_bytes<TB>();
+  if (raised.first())
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w8_rows_kernel<TB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int tiles = (a.K + FR_BN - 1) / FR_BN;
+  hipLaunchKernelGGL((gemm_w8_rows_kernel<TB>), dim3(tiles * a.nsplit), dim3(320), lds, s, a);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+__global__ void rows_f32_to_f16_kernel(const float* __restrict__ x, int64_t ldx, _Float16* __restrict__ y,
+                                       int32_t M, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / (M / 4), c = (i % (M / 4)) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * ldx + c);
+    f16x4 h;
+    h[0] = sat_f16(v[0]); h[1] = sat_f16(v[1]); h[2] = sat_f16(v[2]); h[3] = sat_f16(v[3]);
+    *reinterpret_cast<f16x4*>(y + t * M + c) = h;
+  }
+}
+
+static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, const float* scales,
+                    int32_t group_size, float* y0, int64_t ld0, float* y1, int64_t ld1, float* y2, int64_t ld2,
+                    int32_t k0, int32_t k1, const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
+                    void* split_ws, size_t split_ws_bytes, hipStream_t s) {
+  if (!X || !w || !scales || !y0 || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
+  if (!y1 && !y2) { k0 = K; k1 = K; }
+  if (k0 < 0 || k1 < k0 || k1 > K) return KX_EINVAL;
+  if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
+  const int xalign = x_half ? 8 : 4;
+  // M % 256: a row's scales then start on a 16-byte boundary
+  if (T > 64 || group_size != 64 || M % 256 != 0 || ldx % xalign != 0 || ((uintptr_t)X % 16) != 0 ||
+      ((uintptr_t)w % 16) != 0 || ((uintptr_t)scales % 16) != 0)
+    return KX_EUNSUPPORTED;
+  const int tiles = (K + FR_BN - 1) / FR_BN, nu = M / FR_KU;
+  if (tiles > (int)(kRowsTicketBytes / 4)) return KX_EUNSUPPORTED;
+  // the kernel addresses its operands with 32-bit byte offsets
+  if ((uint64_t)K * (uint64_t)M >= (1ull << 32) || (uint64_t)T * (uint64_t)ldx * 2ull >= (1ull << 32))
+    return KX_EUNSUPPORTED;
+  char* ws = static_cast<char*>(split_ws);
+  const bool have_ws = ws && split_ws_bytes > kRowsTicketBytes + kRowsX16Bytes;
+  if (!x_half) {
+    // fp32 rows: an fp16 copy in the workspace first (the kernel takes fp16 rows only)
+    if (!have_ws || (size_t)T * M * 2 > kRowsX16Bytes) return KX_EUNSUPPORTED;
+    _Float16* x16 = reinterpret_cast<_Float16*>(ws + kRowsTicketBytes);
+    const int64_t n4 = (int64_t)T * (M / 4);
+    hipLaunchKernelGGL(rows_f32_to_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(X), ldx, x16, M, n4);
+    KX_LAUNCH_CHECK();
+    X = x16;
+    ldx = M;
+  }
+  const int TB = T <= 16 ? 1 : T <= 32 ? 2 : 4;
+  const size_t slab_bytes = have_ws ? split_ws_bytes - kRowsTicketBytes - kRowsX16Bytes : 0;
+  int S = rows_split_choice(tiles, nu, TB, slab_bytes);
+  if (const char* e = getenv("KX_ROWS_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
+    const int want = atoi(e);
+    if (want == 1 || ((want == 2 || want == 4 || want == 8 || want == 16) && nu >= want &&
+                      (size_t)tiles * want * TB * 8192 <= slab_bytes))
+      S = want;
+  }
+  RowsArgs a{};
+  a.X = static_cast<const _Float16*>(X); a.w = w; a.scales = scales; a.residual = residual;
+  a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
+  a.ldx = ldx; a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
+  a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
+  a.nsplit = S;
+  a.tickets = reinterpret_cast<unsigned*>(ws);
+  a.slabs = have_ws ? reinterpret_cast<float*>(ws + kRowsTicketBytes + kRowsX16Bytes) : nullptr;
+  switch (TB) {
+    case 1: return launch_rows<1>(a, s);
+    case 2: return launch_rows<2>(a, s);
+    default: return launch_rows<4>(a, s);
+  }
+}
+
+}  // namespace kx
+
+extern "C" int kx_gemm_w8_rows_f32(const float* X, int64_t ldx, const int8_t* w, const float* scales,
+                                   int32_t group_size, float* y0, int64_t ld0, float* y1, int64_t ld1,
+                                   float* y2, int64_t ld2, int32_t k0, int32_t k1, const float* residual,
+                                   int64_t ldr, int32_t T, int32_t M, int32_t K, void* split_workspace,
+                                   size_t split_workspace_bytes, void* stream) {
+  return kx::rows_run(X, false, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
+                      T, M, K, split_workspace, split_workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int kx_gemm_w8_rows_f16act(const void* X16, int64_t ldx, const int8_t* w, const float* scales,
+                                      int32_t group_size, float* y0, int64_t ld0, float* y1, int64_t ld1,
+                                      float* y2, int64_t ld2, int32_t k0, int32_t k1, const float* residual,
+                                      int64_t ldr, int32_t T, int32_t M, int32_t K, void* split_workspace,
+                                      size_t split_workspace_bytes, void* stream) {
+  return kx::rows_run(X16, true, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
+                      T, M, K, split_workspace, split_workspace_bytes, (hipStream_t)stream);
+}

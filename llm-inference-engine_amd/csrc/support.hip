@@ -157,8 +157,9 @@ __global__ void swiglu_kernel(const float* __restrict__ a, const float* __restri
 
 // Row-batched SwiGLU over a stacked [gate | up] activation: out[t][h] = silu(in[t][h]) *
 // in[t][half + h] (the prefill form of swiglu_kernel_cu_fp32).
+template <typename OutT>
 __global__ void swiglu_rows_kernel(const float* __restrict__ in, int64_t ld_in, int half,
-                                   float* __restrict__ out, int64_t ld_out, int rows) {
+                                   OutT* __restrict__ out, int64_t ld_out, int rows) {
   const int64_t n4 = (int64_t)rows * (half / 4);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -171,7 +172,13 @@ __global__ void swiglu_rows_kernel(const float* __restrict__ in, int64_t ld_in, 
     o.y = g.y * (1.0f / (1.0f + expf(-g.y))) * u.y;
     o.z = g.z * (1.0f / (1.0f + expf(-g.z))) * u.z;
     o.w = g.w * (1.0f / (1.0f + expf(-g.w))) * u.w;
-    *reinterpret_cast<f32x4*>(out + t * ld_out + h) = o;
+    if constexpr (sizeof(OutT) == 4) {
+      *reinterpret_cast<f32x4*>(out + t * ld_out + h) = o;
+    } else {
+      f16x4 o16;
+      o16[0] = sat_f16(o.x); o16[1] = sat_f16(o.y); o16[2] = sat_f16(o.z); o16[3] = sat_f16(o.w);
+      *reinterpret_cast<f16x4*>(out + t * ld_out + h) = o16;
+    }
   }
 }
 
@@ -616,8 +623,20 @@ extern "C" int kx_swiglu_rows_f32(const float* in, int64_t ld_in, int32_t half, 
                                   int64_t ld_out, int32_t rows, void* stream) {
   if (!in || !out || half <= 0 || rows <= 0) return KX_EINVAL;
   if (half % 4 || ld_in % 4 || ld_out % 4 || ((uintptr_t)in | (uintptr_t)out) % 16) return KX_EINVAL;
-  hipLaunchKernelGGL(swiglu_rows_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, in, ld_in,
+  hipLaunchKernelGGL(swiglu_rows_kernel<float>, dim3(2048), dim3(256), 0, (hipStream_t)stream, in, ld_in,
                      half, out, ld_out, rows);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_swiglu_rows_f16out(const float* in, int64_t ld_in, int32_t half, void* out16,
+                                     int64_t ld_out, int32_t rows, void* stream) {
+  if (!in || !out16 || half <= 0 || rows <= 0) return KX_EINVAL;
+  if (half % 4 || ld_in % 4 || ld_out % 4 || (uintptr_t)in % 16 || (uintptr_t)out16 % 8) return KX_EINVAL;
+  const int64_t n4 = (int64_t)rows * (half / 4);
+  hipLaunchKernelGGL(swiglu_rows_kernel<_Float16>, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)),
+                     dim3(256), 0, (hipStream_t)stream, in, ld_in, half, static_cast<_Float16*>(out16), ld_out,
+                     rows);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

@@ -1028,10 +1028,15 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     // rows: 6.2 / 9.1 / 11.7 ms against 16.9 / 18.4 / 22.4 ms for the int8 single-pass kernel).
     // Which form a prompt takes depends on its length and on that one decision only, never on
     // which prompts came before it.
-    if (f16_ok && rows >= 32) ST_RET(reserve_weight_images());
+    // Up to 64 rows the int8 weights are streamed once against all rows (kx_gemm_w8_rows_f16act):
+    // bound by the weight bytes like a decode step, no fp16 image involved (Llama-3-8B, 16 / 32 /
+    // 64 rows: see the figures in the design notes).
+    const bool few_rows = rows <= 64 && gs == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 &&
+                          !getenv("KX_PREFILL_NO_ROWS_KERNEL");  // the switch: A/B runs and tests
+    if (!few_rows && f16_ok && rows >= 32) ST_RET(reserve_weight_images());
     int32_t f16_min_rows = weight_images_ == 1 ? 32 : 512;
     if (const char* e = getenv("KX_PREFILL_F16_MIN_ROWS")) f16_min_rows = atoi(e);  // A/B runs
-    const bool f16_chunk = f16_ok && rows >= f16_min_rows;
+    const bool f16_chunk = !few_rows && f16_ok && rows >= f16_min_rows;
     for (int32_t l = 0; l < c.layer_num; ++l) {
       LayerWeights& lw = layers_[l];
       auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
@@ -1040,6 +1045,31 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
       const float* bq = lw.qkv.bias;  // q | k | v biases of the layer, or none
       const float* bk = bq ? bq + ql : nullptr;
       const float* bv = bq ? bq + ql + kl : nullptr;
+      if (few_rows) {
+        // fp16 activation rows (XN / ATT / HH reused as fp16 rows), fp32 results; bias and RoPE,
+        // SwiGLU and the residual sums as in the other forms
+        auto rows_gemm = [&](const void* x16, int64_t ldx, Linear& lin, float* y0, int64_t ld0, float* y1,
+                             int64_t ld1, float* y2, int64_t ld2, int32_t k0, int32_t k1, const float* resid,
+                             int32_t Mm, int32_t Kk) -> int {
+          return kx_gemm_w8_rows_f16act(x16, ldx, static_cast<const int8_t*>(lin.w), lin.s, gs, y0, ld0, y1, ld1,
+                                        y2, ld2, k0, k1, resid, dim, rows, Mm, Kk, split_ws, split_ws_bytes, st);
+        };
+        KX_RET(kx_rmsnorm_f16out(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
+        KX_RET(rows_gemm(XN, dim, lw.qkv, Q, ql, krow, kl, vrow, kl, ql, ql + kl, nullptr, dim, lw.qkv.rows));
+        KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
+                                p0, rows, sin_, cos_, st));
+        if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
+        KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
+        KX_RET(rows_gemm(ATT, ql, lw.wo, X, dim, nullptr, 0, nullptr, 0, dim, dim, res, ql, dim));
+        ST_RET(all_reduce(X, (size_t)rows * dim));
+        KX_RET(kx_rmsnorm_f16out(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
+        KX_RET(rows_gemm(XN, dim, lw.w13, H13, 2 * hl, nullptr, 0, nullptr, 0, 2 * hl, 2 * hl, nullptr, dim,
+                         2 * hl));
+        KX_RET(kx_swiglu_rows_f16out(H13, 2 * hl, hl, HH, hl, rows, st));
+        KX_RET(rows_gemm(HH, hl, lw.w2, X, dim, nullptr, 0, nullptr, 0, dim, dim, res, hl, dim));
+        ST_RET(all_reduce(X, (size_t)rows * dim));
+        continue;
+      }
       if (f16_chunk) {
         // fp16 weight image: the matrix's own kept one (made by the first pass over it), else scratch
         auto gemm16 = [&](const void* x16, Linear& lin, int mode, void* h16, float* y0, int64_t ld0,

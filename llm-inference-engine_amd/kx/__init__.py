@@ -76,6 +76,11 @@ SIGNATURES = {
     "kx_gemm_w8_f16act_split_ws": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int64, _vp, C.c_int64,
                                              _vp, C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32,
                                              _vp, _sz, _vp, _sz, _vp]),
+    "kx_gemm_w8_rows_f32": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
+                                      C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "kx_gemm_w8_rows_f16act": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
+                                         C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp, _sz,
+                                         _vp]),
     "kx_rmsnorm_f16out": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_flash_attention_f16out": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                             _i32, _f, _i32, _vp, _sz, _vp]),
@@ -106,6 +111,7 @@ SIGNATURES = {
                                    _i32, _i32, _vp, _vp, _vp]),
     "kx_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "kx_swiglu_rows_f32": (C.c_int, [_vp, C.c_int64, _i32, _vp, C.c_int64, _i32, _vp]),
+    "kx_swiglu_rows_f16out": (C.c_int, [_vp, C.c_int64, _i32, _vp, C.c_int64, _i32, _vp]),
     "kx_add_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "kx_embedding_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "kx_embedding_dpos_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -403,6 +409,30 @@ def rmsnorm_f16out(x, weight, eps=1e-5):
     out = Buf.zeros((rows, dim), np.float16)
     check(lib().kx_rmsnorm_f16out(dx.ptr, dw.ptr, out.ptr, dim, rows, eps, None), "kx_rmsnorm_f16out")
     return out.numpy(np.float16, (rows, dim))
+
+
+def gemm_w8_rows(X, w, s, group_size=64, split_ws=None, half=False, k0=None, k1=None, residual=None):
+    """Few-row product (T <= 64): returns Y[T][K], or (y0, y1, y2) when k0/k1 route weight-row ranges.
+    half: hand the rows over as fp16.  split_ws: a zero-filled Buf of kx_gemm_split_workspace_bytes()."""
+    K, M = w.shape
+    T = X.shape[0]
+    dx = Buf.from_numpy(X.astype(np.float16 if half else np.float32))
+    dw, ds = Buf.from_numpy(w.astype(np.int8)), Buf.from_numpy(s.astype(np.float32))
+    sp, spb = (split_ws.ptr, split_ws.nbytes) if split_ws is not None else (None, 0)
+    fn = lib().kx_gemm_w8_rows_f16act if half else lib().kx_gemm_w8_rows_f32
+    name = "kx_gemm_w8_rows_f16act" if half else "kx_gemm_w8_rows_f32"
+    dr = Buf.from_numpy(residual.astype(np.float32)) if residual is not None else None
+    if k0 is None:
+        dy = Buf.zeros((T, K))
+        check(fn(dx.ptr, M, dw.ptr, ds.ptr, group_size, dy.ptr, K, None, 0, None, 0, K, K,
+                 dr.ptr if dr else None, K if dr else 0, T, M, K, sp, spb, None), name)
+        sync()
+        return dy.numpy()
+    y0, y1, y2 = Buf.zeros((T, k0)), Buf.zeros((T, k1 - k0)), Buf.zeros((T, K - k1))
+    check(fn(dx.ptr, M, dw.ptr, ds.ptr, group_size, y0.ptr, k0, y1.ptr, k1 - k0, y2.ptr, K - k1, k0, k1,
+             dr.ptr if dr else None, k0 if dr else 0, T, M, K, sp, spb, None), name)
+    sync()
+    return y0.numpy(), y1.numpy(), y2.numpy()
 
 
 def gemm_w8(X, w, s, group_size=64, two_pass=False):

@@ -560,6 +560,104 @@ def test_gemm_w8_vs_oracle(T, K, M):
     assert np.sqrt((err ** 2).mean()) <= 1e-4 * np.sqrt((absum ** 2).mean())
 
 
+def _w8_tol(X, w, s, want):
+    K, M = w.shape
+    sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
+    return 2.0 ** -11 * (np.abs(X.astype(np.float64)) @ sd.T) + 1e-7 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("T,K,M", [(2, 384, 1024), (16, 200, 1536), (17, 130, 2304), (33, 640, 512),
+                                   (48, 96, 256), (64, 1000, 1280)])
+def test_gemm_w8_few_rows_vs_oracle(monkeypatch, half, T, K, M):
+    # 2..64 rows against the int8 weight stream: same arithmetic as the tiled int8 kernel (rows rounded
+    # to fp16, fp32 group sums times fp32 scales); every cut of the reduction gives the bound, the
+    # same bits when repeated, and leaves the arrival tickets at zero
+    rng = np.random.default_rng(T * 1000 + K + M)
+    _, w, s = rand_w8(rng, K, M)
+    X = rng.standard_normal((T, M)).astype(np.float32)
+    if half:
+        X = X.astype(np.float16).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    tol = _w8_tol(X, w, s, want)
+    sp = kx.Buf.zeros(kx.lib().kx_gemm_split_workspace_bytes(), np.uint8)
+    for parts in ("", "1", "2", "4", "8"):
+        if parts and M // 128 < int(parts):
+            continue
+        if parts:
+            monkeypatch.setenv("KX_ROWS_SPLIT", parts)
+        else:
+            monkeypatch.delenv("KX_ROWS_SPLIT", raising=False)
+        got = kx.gemm_w8_rows(X, w, s, GS, split_ws=sp, half=half)
+        assert np.all(np.abs(got - want) <= tol), parts
+        np.testing.assert_array_equal(got, kx.gemm_w8_rows(X, w, s, GS, split_ws=sp, half=half))
+    assert not sp.numpy()[:4096].any()
+
+
+def test_gemm_w8_few_rows_routing_residual_and_refusals():
+    # weight-row ranges to three destinations (q | k | v) and a residual on the first, as the tiled
+    # kernels take them; shapes the kernel is not built for are refused, not approximated
+    rng = np.random.default_rng(11)
+    T, K, M, k0, k1 = 40, 640, 768, 384, 512
+    _, w, s = rand_w8(rng, K, M)
+    X = rng.standard_normal((T, M)).astype(np.float16).astype(np.float32)
+    res = rng.standard_normal((T, k0)).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    tol = _w8_tol(X, w, s, want)
+    sp = kx.Buf.zeros(kx.lib().kx_gemm_split_workspace_bytes(), np.uint8)
+    for half in (False, True):
+        y0, y1, y2 = kx.gemm_w8_rows(X, w, s, GS, split_ws=sp, half=half, k0=k0, k1=k1, residual=res)
+        assert np.all(np.abs(y0 - (want[:, :k0] + res)) <= tol[:, :k0] + 1e-6)
+        assert np.all(np.abs(y1 - want[:, k0:k1]) <= tol[:, k0:k1])
+        assert np.all(np.abs(y2 - want[:, k1:]) <= tol[:, k1:])
+    dx, dw, ds = kx.Buf.from_numpy(X), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)
+    dy = kx.Buf.zeros((80, K))
+    call = lambda T_, M_, gs: kx.lib().kx_gemm_w8_rows_f32(dx.ptr, M_, dw.ptr, ds.ptr, gs, dy.ptr, K, None, 0, None,
+                                                           0, K, K, None, 0, T_, M_, K, sp.ptr, sp.nbytes, None)
+    # -2 = KX_EUNSUPPORTED
+    assert call(65, M, GS) == -2          # more than 64 rows
+    assert call(T, 192, GS) == -2         # reduction not a multiple of 256
+    assert call(T, M, 128) == -2          # other group sizes
+    assert kx.lib().kx_gemm_w8_rows_f32(dx.ptr, M, dw.ptr, ds.ptr, GS, dy.ptr, K, None, 0, None, 0, K, K, None,
+                                        0, T, M, K, None, 0, None) == -2  # fp32 rows need the workspace
+
+
+@pytest.mark.parametrize("T,K,M,k0,k1", [(48, 6144, 4096, 4096, 5120), (64, 4096, 14336, 4096, 4096),
+                                          (24, 28672, 4096, 28672, 28672), (32, 3072, 2048, 2048, 2560)])
+def test_gemm_w8_few_rows_full_size(T, K, M, k0, k1):
+    # Llama-3-8B (and one Llama-3.2-1B) matrices at full size, checked on a sample of weight rows
+    rng = np.random.default_rng(K + M)
+    _, w, s = rand_w8(rng, K, M)
+    X = rng.standard_normal((T, M)).astype(np.float16)
+    sp = kx.Buf.zeros(kx.lib().kx_gemm_split_workspace_bytes(), np.uint8)
+    if k0 < K:
+        y = np.concatenate(kx.gemm_w8_rows(X.astype(np.float32), w, s, GS, split_ws=sp, half=True, k0=k0, k1=k1),
+                           axis=1)
+    else:
+        y = kx.gemm_w8_rows(X.astype(np.float32), w, s, GS, split_ws=sp, half=True)
+    rows = np.unique(np.r_[0, K - 1, rng.integers(0, K, 200)])
+    ws, ss = w[rows], s.reshape(K, M // GS)[rows].reshape(-1)
+    want = kxo.gemm_w8(X.astype(np.float32), ws, ss, GS, threads=8)
+    assert np.all(np.abs(y[:, rows] - want) <= _w8_tol(X.astype(np.float32), ws, ss, want))
+    assert not sp.numpy()[:4096].any()
+
+
+def test_swiglu_rows_fp16_result():
+    rng = np.random.default_rng(3)
+    T, half = 37, 1024
+    H = (rng.standard_normal((T, 2 * half)) * 3).astype(np.float32)
+    H[0, 0], H[0, half] = 300.0, 400.0                    # 120000 in fp32: saturates, no infinity
+    din, dout = kx.Buf.from_numpy(H), kx.Buf.zeros((T, half), np.float16)
+    kx.check(kx.lib().kx_swiglu_rows_f16out(din.ptr, 2 * half, half, dout.ptr, half, T, None), "swiglu16")
+    kx.sync()
+    g, u = H[:, :half].astype(np.float64), H[:, half:].astype(np.float64)
+    ref = g / (1.0 + np.exp(-g)) * u
+    got = dout.numpy().astype(np.float64)
+    assert got[0, 0] == 65504.0
+    ref[0, 0] = 65504.0
+    assert np.all(np.abs(got - ref) <= 2.0 ** -10 * np.abs(ref) + 1e-6)
+
+
 @pytest.mark.parametrize("T,K,M", [(512, 128, 128), (533, 200, 256), (700, 384, 1024), (1100, 200, 128)])
 def test_gemm_w8_two_pass_vs_oracle(T, K, M):
     # long-prompt form: X and scale*w each rounded once to fp16 (2^-11 relative, per element)
