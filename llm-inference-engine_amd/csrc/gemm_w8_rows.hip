@@ -14,9 +14,12 @@
 //     wave 4 only brings in the activation rows.
 //   - everything arrives by LDS-DMA (global_load_lds, 16 bytes per lane), so loads in flight hold
 //     no registers and are waited for with hand-counted vmcnt.  A compute wave keeps a private
-//     ring of five unit slots (4 KiB of weights + the rows' scales each) and requests unit u + 4
-//     before it multiplies unit u: 12-16 KiB per wave in flight.  The activation units (T rows x
-//     128 halves) are shared, in three or four buffers; wave 4 requests them two or three units
+//     ring of three unit slots (4 KiB of weights each) and requests unit u + 2 before it
+//     multiplies unit u; the rows' scales come 32 bytes per row at a time (four units' worth, one
+//     instruction) into a small ring of their own.  A deeper ring did not stream faster (six slots:
+//     W1|W3 of Llama-3-8B at 16 rows 31.7 us against 30.1); a second workgroup on the CU, for which
+//     the short ring leaves the LDS, does (26.0).  The activation units (T rows x
+//     128 halves) are shared, in two to four buffers; wave 4 requests them one to three units
 //     ahead and waits for them on its own counter, so that wait never drains the compute waves'
 //     weight prefetch (loads complete in order within a wave).
 //   - one DMA instruction covers 8 rows x 128 contiguous bytes (16 rows x 64 bytes, the
@@ -42,10 +45,11 @@ using lds_ptr_t = __attribute__((address_space(3))) void*;
 
 constexpr int FR_BN = 128;     // weight rows per workgroup
 constexpr int FR_KU = 128;     // reduction elements per unit
-constexpr int FR_RING = 5;     // weight unit slots per compute wave
+constexpr int FR_RING = 3;     // weight unit slots per compute wave
 constexpr int FR_AHEAD = FR_RING - 1;
-constexpr int FR_SLOT = 5120;  // 4 x 1 KiB of weights + 1 KiB of scales
-constexpr int FR_NW = 5;       // DMA instructions per weight unit and wave
+constexpr int FR_SLOT = 4096;  // one unit of a wave's 32 rows
+constexpr int FR_SRING = 3;    // scale slots per compute wave: 1 KiB = the scales of four units
+constexpr int FR_WAVE_LDS = FR_RING * FR_SLOT + FR_SRING * 1024;
 constexpr size_t kRowsTicketBytes = 4096;
 constexpr size_t kRowsX16Bytes = 4u << 20;  // fp16 copy of fp32 activation rows (64 x 32768 at most)
 
@@ -80,17 +84,17 @@ __device__ __forceinline__ f16x8 cvt_w8x8(uint32_t d0, uint32_t d1) {
   return __builtin_bit_cast(f16x8, r);
 }
 
-// waits until at most `units` weight units (FR_NW instructions each) are still in flight
-__device__ __forceinline__ void wait_units(int units) {
-  switch (units) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+// waits until at most `n` of this wave's DMA instructions are still in flight
+__device__ __forceinline__ void wait_dma(int n) {
+#define KX_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    KX_W(0) KX_W(1) KX_W(2) KX_W(3) KX_W(4) KX_W(5) KX_W(6) KX_W(7) KX_W(8) KX_W(9) KX_W(10) KX_W(11)
+    KX_W(12) KX_W(13) KX_W(14) KX_W(15) KX_W(16) KX_W(17) KX_W(18) KX_W(19) KX_W(20) KX_W(21)
+    default: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
   }
+#undef KX_W
 }
-static_assert(FR_NW == 5 && FR_AHEAD == 4, "wait_units spells these counts out");
+static_assert(4 * FR_AHEAD + 2 <= 22, "wait_dma covers the units in flight and their scale fetches");
 
 template <int S, int TB>
 __device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TB], __amdgpu_buffer_rsrc_t rs, unsigned lane_off) {
@@ -116,10 +120,10 @@ __device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TB], __amdgpu_buffe
 
 // activation unit buffers: as many as LDS has room for beside the weight rings
 template <int TB>
-constexpr int rows_xbufs() { return TB == 4 ? 3 : 4; }
-// LDS: [activation unit buffers: TB x 4 KiB each][weight rings: 4 waves x FR_RING x FR_SLOT]
+constexpr int rows_xbufs() { return TB == 1 ? 4 : TB == 2 ? 2 : 3; }
+// LDS: [activation unit buffers: TB x 4 KiB each][per compute wave: weight ring, scale ring]
 template <int TB>
-constexpr int rows_lds_bytes() { return rows_xbufs<TB>() * TB * 4096 + 4 * FR_RING * FR_SLOT; }
+constexpr int rows_lds_bytes() { return rows_xbufs<TB>() * TB * 4096 + 4 * FR_WAVE_LDS; }
 
 template <int TB>
 __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) {
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
   }
   constexpr int NXB = rows_xbufs<TB>();
   char* const xbuf = smem;
-  char* const ring = smem + NXB * XBUF + (wave & 3) * (FR_RING * FR_SLOT);
+  char* const ring = smem + NXB * XBUF + (wave & 3) * FR_WAVE_LDS;
+  char* const sring = ring + FR_RING * FR_SLOT;
 
   f32x4 acc[2][TB];
 #pragma unroll
@@ -203,8 +208,9 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
         woff[rb][h] = n * (unsigned)a.M + (unsigned)u0 * FR_KU + (unsigned)(((lane & 7) ^ key) * 16);
       }
     {
+      // lanes 0-31: the rows' first 16 bytes of a four-unit block of scales, lanes 32-63: the second
       const unsigned n = (unsigned)min(n0 + wave * 32 + (lane & 31), a.K - 1);
-      soff = n * (unsigned)(a.M / 64) * 4u;
+      soff = n * (unsigned)(a.M / 64) * 4u + (unsigned)(lane >> 5) * 16u;
     }
     const char* const wbase = reinterpret_cast<const char*>(a.w);
     const char* const sbase = reinterpret_cast<const char*>(a.scales);
@@ -216,11 +222,14 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
         for (int h = 0; h < 2; ++h)
           __builtin_amdgcn_global_load_lds(
               reinterpret_cast<const uint32_t*>(wbase + (woff[rb][h] + (unsigned)u * FR_KU)),
-              (lds_ptr_t)(dst + (rb * 2 + h) * 1024), 16, 0, 0);
-      // the 16 bytes of scales that hold this unit's two groups (four groups per 16 bytes)
-      __builtin_amdgcn_global_load_lds(
-          reinterpret_cast<const uint32_t*>(sbase + (soff + (unsigned)((u0 + u) >> 1) * 16u)),
-          (lds_ptr_t)(dst + 4096), 16, 0, 0);
+              (lds_ptr_t)(dst + (rb * 2 + h) * 1024), 16, 0, 2);  // 2 = nt: streamed once
+      // the 32 bytes of scales per row that hold this and the next three units' groups, fetched
+      // with the first unit of such a block (or of this part)
+      const int U = u0 + u;
+      if ((U & 3) == 0 || u == 0)
+        __builtin_amdgcn_global_load_lds(
+            reinterpret_cast<const uint32_t*>(sbase + (soff + (unsigned)(U >> 2) * 32u)),
+            (lds_ptr_t)(sring + ((U >> 2) % FR_SRING) * 1024), 16, 0, 0);
     };
     // fragment addresses: lane (j, q) = (lane & 15, lane >> 4)
     const int j = lane & 15, q = lane >> 4;
@@ -239,15 +248,21 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
       if (u < un) issue_w(u);
     for (int u = 0; u < un; ++u) {
       if (u + FR_AHEAD < un) issue_w(u + FR_AHEAD);
-      wait_units(min(FR_AHEAD, un - 1 - u));
+      {
+        // younger than unit u's: four instructions per unit requested since, one more per block of
+        // scales that started among them
+        const int k = min(FR_AHEAD, un - 1 - u);
+        wait_dma(4 * k + (((u0 + u + k) >> 2) - ((u0 + u) >> 2)));
+      }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const char* slot = ring + (u % FR_RING) * FR_SLOT;
       const char* xb = xbuf + (u % NXB) * XBUF;
-      const int sel = ((u0 + u) & 1) * 2;
+      const int U = u0 + u, sel = (U & 1) * 2;
+      const char* sslot = sring + ((U >> 2) % FR_SRING) * 1024 + ((U >> 1) & 1) * 512;
       f32x4 sv[2];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) sv[rb] = *reinterpret_cast<const f32x4*>(slot + 4096 + (rb * 16 + j) * 16);
+      for (int rb = 0; rb < 2; ++rb) sv[rb] = *reinterpret_cast<const f32x4*>(sslot + (rb * 16 + j) * 16);
 #pragma unroll
       for (int gl = 0; gl < 2; ++gl) {
         f16x8 xa[TB][2];
@@ -344,13 +359,15 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
   }
 }
 
-// Parts per tile: one workgroup per CU is what LDS allows, so the reduction is cut until the
-// grid has about as many workgroups as the chip has CUs; never so finely that a part is left with
-// fewer units than the ring prefetches.
+// Parts per tile.  Up to 32 rows two workgroups fit a CU's LDS, and twice the waves keep more
+// requests in flight than a deeper ring does: matrices with many tiles are cut until the grid has
+// up to two workgroups per CU, narrow ones (where a part is short and the last arriver's sum of S
+// slabs shows) up to one.  Measured on Llama-3-8B's matrices, 16 rows: Wq|Wk|Wv 25.7 / 15.8 / 11.1 /
+// 11.1 / 15.7 us for 1 / 2 / 4 / 8 / 16 parts, W1|W3 28.8 / 24.6 / 29.2 / 34.9, Wo 8.8 at 8.
 static int rows_split_choice(int tiles, int nu, int TB, size_t slab_bytes) {
+  const int cap = TB <= 2 && tiles >= 128 ? 512 : 256;
   int S = 1;
-  while (S < 16 && tiles * S * 2 <= 256 && nu >= 4 * S && (size_t)tiles * (2 * S) * TB * 8192 <= slab_bytes)
-    S *= 2;
+  while (S < 16 && tiles * S * 2 <= cap && nu >= 4 * S && (size_t)tiles * (2 * S) * TB * 8192 <= slab_bytes) S *= 2;
   return S;
 }
 
