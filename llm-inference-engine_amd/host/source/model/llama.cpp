@@ -1023,14 +1023,15 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     // per-layer GEMM time of the two forms on the 8B matrices ties at 512..640 rows; the fp16 form
     // also saves the separate SwiGLU pass
     // ... while the fp16 weight images have to be made per pass.  A model that keeps its images
-    // (prefill_weight_cache, decided here at the first prompt of 32+ rows) pays the conversion once
+    // (prefill_weight_cache, decided here at the first prompt that is not run by the few-rows
+    // kernel below and has 32+ rows) pays the conversion once
     // per matrix, and from then on the fp16 form wins from 32 rows up (Llama-3-8B, 32 / 128 / 384
     // rows: 6.2 / 9.1 / 11.7 ms against 16.9 / 18.4 / 22.4 ms for the int8 single-pass kernel).
     // Which form a prompt takes depends on its length and on that one decision only, never on
     // which prompts came before it.
     // Up to 64 rows the int8 weights are streamed once against all rows (kx_gemm_w8_rows_f16act):
     // bound by the weight bytes like a decode step, no fp16 image involved (Llama-3-8B, 16 / 32 /
-    // 64 rows: see the figures in the design notes).
+    // 64 rows: 3.2 / 3.6 / 4.6 ms against 16.4 / 6.0 / 7.0 ms for the tiled kernels).
     const bool few_rows = rows <= 64 && gs == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 &&
                           !getenv("KX_PREFILL_NO_ROWS_KERNEL");  // the switch: A/B runs and tests
     if (!few_rows && f16_ok && rows >= 32) ST_RET(reserve_weight_images());
