@@ -432,7 +432,9 @@ static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* wor
   const size_t half_bytes = (size_t)kvh * s_pad * HS * 2;
   const bool have_ws = workspace && workspace_bytes >= FA_WS_SKIP + 2 * half_bytes;
   if (a.kc16 && !have_ws) return KX_EWORKSPACE;  // a 16-bit cache is only read through the copies
-  if (have_ws) {
+  // up to three key tiles the copies cost a launch (4 us) for nothing: the tiles are converted once
+  // or twice each on their way into LDS anyway
+  if (have_ws && (a.kc16 || a.pos >= 3 * FA_KV)) {
     char* ws = static_cast<char*>(workspace) + FA_WS_SKIP;
     _Float16* k16 = reinterpret_cast<_Float16*>(ws);
     _Float16* v16t = reinterpret_cast<_Float16*>(ws + half_bytes);
