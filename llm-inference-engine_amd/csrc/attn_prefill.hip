@@ -28,7 +28,6 @@ namespace kx {
 
 constexpr int FA_KV = 64;       // keys per tile
 constexpr int FA_VT_ROW = 68;   // halves per padded V^T row (64 keys + 4), fp32-source path
-constexpr int FA_VT_ROW16 = 72; // same for the fp16-source path (16-byte aligned rows)
 constexpr size_t FA_WS_SKIP = 16384;  // head of the workspace left alone (decode arrival tickets)
 
 // fp16 copies of one layer's K and V rows 0..pos, made once per call when the caller provides the
@@ -93,21 +92,60 @@ struct FaArgs {
   int32_t s_pad;
 };
 
-// F16SRC: K/V tiles come from the fp16 copies (16-byte copies into LDS, no conversion) instead of
-// the fp32 cache rows.
-template <int HS, bool F16SRC>
-__global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
-  constexpr int K_ROW = HS + 8;         // halves per padded K row
+#ifdef FA_TRACE
+// diagnostic build only (tools/fa_trace.py): cycles per loop phase of the heaviest workgroup
+__device__ unsigned long long fa_trace_buf[8][16];
+#define FA_STAMP(i)                                                 \
+  do {                                                              \
+    if (traced) {                                                   \
+      const unsigned long long now_ = __builtin_readcyclecounter(); \
+      tr_acc[i] += now_ - tr_last;                                  \
+      tr_last = now_;                                               \
+    }                                                               \
+  } while (0)
+#else
+#define FA_STAMP(i)
+#endif
+
+// max of a value with its partner 32 lanes away, in every lane: one v_permlane32_swap hands each
+// half of the wave the other half's values (no trip through LDS as ds_bpermute takes)
+__device__ __forceinline__ float fa_halves_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+// DMA: the K/V tiles come from the fp16 copies by LDS-DMA (global_load_lds: 1 KiB per wave
+// instruction straight into LDS, no staging registers, no ds_write pass; the first NW waves of
+// the workgroup bring in 1/NW of a tile's pieces each).  An instruction fills LDS linearly, so rows cannot
+// be padded: 16-byte chunk c of a row sits at chunk position c ^ key(row) instead -- applied to the
+// SOURCE address when filling and to the LDS address when reading -- with the key chosen so that
+// the 16 rows read by 16 consecutive lanes cover all 64 banks.
+// !DMA: the fp32 cache rows are rounded to fp16 on their way through registers into padded images
+// (no workspace, or a cache of at most three tiles).
+template <int HS, bool DMA, int NW>
+__device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
+  constexpr int K_ROW = HS + 8;         // halves per padded K row (!DMA)
   constexpr int KS = HS / 16;           // 16-dim MFMA steps of Q.K
   constexpr int DT = HS / 32;           // 32-dim output tiles
   constexpr int K_TILE = FA_KV * K_ROW; // halves
-  constexpr int VT_ROW = F16SRC ? FA_VT_ROW16 : FA_VT_ROW;
+  constexpr int VT_ROW = FA_VT_ROW;
   constexpr int V_TILE = HS * VT_ROW;
   constexpr int BUF = K_TILE + V_TILE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // DMA images: K [64 keys][HS] and V^T [HS][64 keys], unpadded
+  constexpr int DK_ROWB = HS * 2;               // bytes per K row
+  constexpr int DK_TILE_B = FA_KV * DK_ROWB;
+  constexpr int DV_TILE_B = HS * FA_KV * 2;     // V^T rows are 128 bytes
+  constexpr int DBUF_B = DK_TILE_B + DV_TILE_B;
+  constexpr int DK_PIECES = DK_TILE_B / 1024;
+  constexpr int DPER = DMA ? (DK_TILE_B + DV_TILE_B) / 1024 / NW : 1;  // pieces per wave and tile
+  constexpr int DKCH = DK_ROWB / 16;            // 16-byte chunks per K row
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using lds_ptr_t = __attribute__((address_space(3))) void*;
   _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x;
   const int qcol = lane & 31, half = lane >> 5;
   const int groups_per_kvh = a.kv_mul / a.hpb;
@@ -127,6 +165,39 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   const int last_row_block = min(q0_block + rows_per_block, a.Tq) - 1;
   const int max_key = a.causal ? qpos0 + last_row_block : a.pos;
   const int ntiles = max_key / FA_KV + 1;
+
+  // ---- LDS-DMA roles: piece p = wave + NW i of a tile; pieces 0..DK_PIECES-1 are K rows, the
+  //      rest V^T rows; lane l fills bytes 16 l .. 16 l + 15 of the piece ----
+  const _Float16* dsrc[DPER];
+  int dstep[DPER];  // halves from one tile to the next
+  if constexpr (DMA) {
+    const _Float16* k16base = a.k16 + (size_t)kvh * a.s_pad * HS;
+    const _Float16* v16base = a.v16t + (size_t)kvh * HS * a.s_pad;
+#pragma unroll
+    for (int i = 0; i < DPER; ++i) {
+      const int p = wave % NW + NW * i;
+      if (p < DK_PIECES) {
+        const int row = p * (1024 / DK_ROWB) + lane / DKCH, pos = lane % DKCH;
+        const int chunk = pos ^ ((row * DKCH / 16) % DKCH);
+        dsrc[i] = k16base + (size_t)row * HS + 8 * chunk;
+        dstep[i] = FA_KV * HS;
+      } else {
+        const int d = (p - DK_PIECES) * 8 + (lane >> 3), pos = lane & 7;
+        const int chunk = pos ^ ((d >> 1) & 7);
+        dsrc[i] = v16base + (size_t)d * a.s_pad + 8 * chunk;
+        dstep[i] = FA_KV;
+      }
+    }
+  }
+  auto issue_tile = [&](int t, int buf) {
+    if (wave >= NW) return;  // workgroups of 5..7 waves: the first four bring the tiles in
+#pragma unroll
+    for (int i = 0; i < DPER; ++i)
+      __builtin_amdgcn_global_load_lds(dsrc[i] + (size_t)t * dstep[i],
+                                       (lds_ptr_t)(smem + buf * DBUF_B + (wave + NW * i) * 1024), 16, 0,
+                                       0);
+  };
+  if constexpr (DMA) issue_tile(0, 0);
 
   // ---- Q fragment (B operand): lane (q row, half) holds Q[row][16ks + 8half + j] * scale ----
   // scores are kept in the log2 domain: Q is scaled by softmax_scale * log2(e)
@@ -154,48 +225,31 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
     }
   }
 
-  // ---- staging roles ----
+  // ---- fragment addresses (bytes inside a buffer) ----
+  // DMA: K row qcol (+32 kt), chunk 2ks+half swizzled; V^T row qcol (+32 dt), chunk 4kt+2st+half
+  int koff[DMA ? KS : 1], voff[DMA ? 4 : 1];
+  if constexpr (DMA) {
+    const int kkey = (qcol * DKCH / 16) % DKCH, vkey = (qcol >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = qcol * DK_ROWB + (((2 * ks + half) ^ kkey) << 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voff[j] = DK_TILE_B + qcol * 128 + (((2 * j + half) ^ vkey) << 4);
+  }
+
+  // ---- register staging roles (!DMA) ----
   // K: item = (key, 4-dim group): 64 * HS/4 items.  V: item = (4-key group, 4-dim group).
   constexpr int K_ITEMS = FA_KV * (HS / 4);
   constexpr int V_ITEMS = (FA_KV / 4) * (HS / 4);
   constexpr int MAXT = 256;  // fewest threads a launch uses
   constexpr int K_PER = (K_ITEMS + MAXT - 1) / MAXT;
   constexpr int V_PER = (V_ITEMS + MAXT - 1) / MAXT;
-  // fp16 source: K item = (key, 8-dim chunk), V item = (dim, 8-key chunk), 16 bytes each
-  constexpr int K16_ITEMS = FA_KV * (HS / 8);
-  constexpr int V16_ITEMS = HS * (FA_KV / 8);
-  constexpr int K16_PER = (K16_ITEMS + MAXT - 1) / MAXT;
-  constexpr int V16_PER = (V16_ITEMS + MAXT - 1) / MAXT;
-  f32x4 kreg[F16SRC ? 1 : K_PER];
-  f32x4 vreg[F16SRC ? 1 : V_PER][4];
-  i32x4 kreg16[F16SRC ? K16_PER : 1];
-  i32x4 vreg16[F16SRC ? V16_PER : 1];
+  f32x4 kreg[DMA ? 1 : K_PER];
+  f32x4 vreg[DMA ? 1 : V_PER][4];
   const float* kbase = a.kc + (size_t)kvh * HS;
   const float* vbase = a.vc + (size_t)kvh * HS;
-  const _Float16* k16base = F16SRC ? a.k16 + (size_t)kvh * a.s_pad * HS : nullptr;
-  const _Float16* v16base = F16SRC ? a.v16t + (size_t)kvh * HS * a.s_pad : nullptr;
 
   auto load_tile = [&](int t) {
     const int key0 = t * FA_KV;
-    if constexpr (F16SRC) {
-#pragma unroll
-      for (int i = 0; i < K16_PER; ++i) {
-        const int item = tid + i * nthreads;
-        if (item < K16_ITEMS) {
-          const int key = item / (HS / 8), ch = item % (HS / 8);
-          kreg16[i] = *reinterpret_cast<const i32x4*>(k16base + (size_t)(key0 + key) * HS + 8 * ch);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < V16_PER; ++i) {
-        const int item = tid + i * nthreads;
-        if (item < V16_ITEMS) {
-          const int d = item / (FA_KV / 8), ch = item % (FA_KV / 8);
-          vreg16[i] = *reinterpret_cast<const i32x4*>(v16base + (size_t)d * a.s_pad + key0 + 8 * ch);
-        }
-      }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < K_PER; ++i) {
       const int item = tid + i * nthreads;
@@ -220,25 +274,6 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   auto store_tile = [&](int buf) {
     _Float16* Kl = lds + buf * BUF;
     _Float16* Vl = Kl + K_TILE;
-    if constexpr (F16SRC) {
-#pragma unroll
-      for (int i = 0; i < K16_PER; ++i) {
-        const int item = tid + i * nthreads;
-        if (item < K16_ITEMS) {
-          const int key = item / (HS / 8), ch = item % (HS / 8);
-          *reinterpret_cast<i32x4*>(Kl + key * K_ROW + 8 * ch) = kreg16[i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < V16_PER; ++i) {
-        const int item = tid + i * nthreads;
-        if (item < V16_ITEMS) {
-          const int d = item / (FA_KV / 8), ch = item % (FA_KV / 8);
-          *reinterpret_cast<i32x4*>(Vl + d * VT_ROW + 8 * ch) = vreg16[i];
-        }
-      }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < K_PER; ++i) {
       const int item = tid + i * nthreads;
@@ -278,20 +313,35 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  load_tile(0);
-  store_tile(0);
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
+#ifdef FA_TRACE
+  const bool traced = blockIdx.x == 0 && blockIdx.y == 0;
+  unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tr_last = __builtin_readcyclecounter();
+  const unsigned long long tr_c0 = tr_last, tr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // tiles past this wave's own last query row contribute nothing to it
   const int wave_last_pos = a.causal ? min(qpos0 + min(q0 + 31, a.Tq - 1), a.pos) : a.pos;
 
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) load_tile(t + 1);
+    FA_STAMP(0);
+    if (t + 1 < ntiles) {
+      if constexpr (DMA) issue_tile(t + 1, buf ^ 1); else load_tile(t + 1);
+    }
+    FA_STAMP(1);
     const int key0 = t * FA_KV;
     if (key0 <= wave_last_pos) {
       const _Float16* Kl = lds + buf * BUF;
       const _Float16* Vl = Kl + K_TILE;
+      const char* Dl = smem + buf * DBUF_B;
       // ---- S^T[key][q] for the tile's two 32-key halves ----
       f32x16 s[2];
 #pragma unroll
@@ -301,10 +351,12 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
         const _Float16* kp = Kl + (kt * 32 + qcol) * K_ROW + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + 16 * ks);
+          const f16x8 kf = DMA ? *reinterpret_cast<const f16x8*>(Dl + kt * 32 * DK_ROWB + koff[ks])
+                               : *reinterpret_cast<const f16x8*>(kp + 16 * ks);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
         }
       }
+      FA_STAMP(2);
       // ---- mask + online softmax (one query row per lane; the other half-wave holds the
       //      other 32 keys of the same row) ----
       // only the tiles on the diagonal (or at the end of the cache) hold keys some row must not
@@ -323,7 +375,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-      mx = fmaxf(mx, lane_xor32(mx));
+      mx = fa_halves_max(mx);
       // Lazy running max: the reference point of the exponentials only moves when some row's
       // new maximum exceeds the old one by more than 2^kLazy (scores are in the log2 domain).
       // Softmax does not depend on the reference point; keeping it makes alpha = 1 and skips the
@@ -342,6 +394,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
+      FA_STAMP(3);
       const float m_use = m_run == -INFINITY ? 0.f : m_run;
       float psum = 0.f;
 #pragma unroll
@@ -363,12 +416,11 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
           f16x8 pf;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (_Float16)s[kt][8 * st + j];
-          if constexpr (F16SRC) {
+          if constexpr (DMA) {
             // keys are stored in score-register order: the fragment is one 16-byte read
-            const _Float16* vp = Vl + qcol * VT_ROW + kt * 32 + 16 * st + 8 * half;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-              const f16x8 vf = *reinterpret_cast<const f16x8*>(vp + dt * 32 * VT_ROW);
+              const f16x8 vf = *reinterpret_cast<const f16x8*>(Dl + dt * 32 * 128 + voff[2 * kt + st]);
               o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
             }
           } else {
@@ -385,9 +437,24 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
           }
         }
     }
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    FA_STAMP(4);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile are in
+    } else {
+      if (t + 1 < ntiles) store_tile(buf ^ 1);
+    }
+    FA_STAMP(5);
     __syncthreads();
+    FA_STAMP(6);
   }
+#ifdef FA_TRACE
+  if (traced && lane == 0) {
+    for (int i = 0; i < 8; ++i) fa_trace_buf[wave][i] = tr_acc[i];
+    fa_trace_buf[wave][8] = __builtin_readcyclecounter() - tr_c0;
+    fa_trace_buf[wave][9] = __builtin_amdgcn_s_memrealtime() - tr_r0;
+    fa_trace_buf[wave][10] = ntiles;
+  }
+#endif
 
   // ---- epilogue: lane (q row, half) holds O[row][32dt + 8g + 4half + e] in o[dt][4g+e] ----
   l_run += lane_xor32(l_run);
@@ -411,20 +478,25 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
   }
 }
 
-template <int HS, bool F16SRC>
+// the body lives in a device-only function: the host pass then never instantiates its LDS-DMA calls
+template <int HS, bool DMA, int NW>
+__global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
+  attn_prefill_body<HS, DMA, NW>(a);
+}
+
+template <int HS, bool DMA, int NW>
 static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
-  constexpr int vt_row = F16SRC ? FA_VT_ROW16 : FA_VT_ROW;
-  constexpr size_t lds = 2 * (size_t)(FA_KV * (HS + 8) + HS * vt_row) * 2;
+  constexpr size_t lds = DMA ? 2 * (size_t)(2 * FA_KV * HS * 2)
+                             : 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
   static OncePerDevice raised;
   if (lds > 64 * 1024 && raised.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, F16SRC>),
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, DMA, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid(kvh * (a.kv_mul / a.hpb), qblocks);
-  hipLaunchKernelGGL((attn_prefill_kernel<HS, F16SRC>), grid, dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((attn_prefill_kernel<HS, DMA, NW>), grid, dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
-
 template <int HS>
 static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* workspace,
                           size_t workspace_bytes, hipStream_t s) {
@@ -448,9 +520,10 @@ static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* wor
     a.k16 = k16;
     a.v16t = v16t;
     a.s_pad = s_pad;
-    return launch_prefill_kernel<HS, true>(a, kvh, threads, qblocks, s);
+    if (threads == 512) return launch_prefill_kernel<HS, true, 8>(a, kvh, threads, qblocks, s);
+    return launch_prefill_kernel<HS, true, 4>(a, kvh, threads, qblocks, s);
   }
-  return launch_prefill_kernel<HS, false>(a, kvh, threads, qblocks, s);
+  return launch_prefill_kernel<HS, false, 8>(a, kvh, threads, qblocks, s);
 }
 
 }  // namespace kx
@@ -580,3 +653,9 @@ extern "C" int kx_flash_attention_kv16(const float* query, const void* key_cache
                              Tq, head_num, kv_head_num, head_size, seq_len, pos, layer_idx,
                              softmax_scale, is_causal, workspace, workspace_bytes, stream);
 }
+
+#ifdef FA_TRACE
+extern "C" int kx_fa_trace_read(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(kx::fa_trace_buf), sizeof(kx::fa_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
