@@ -27,6 +27,9 @@
 namespace kx {
 
 constexpr int FA_KV = 64;       // keys per tile
+#ifndef FA_TPB
+#define FA_TPB 1                // tiles per barrier interval (LDS-DMA form)
+#endif
 constexpr int FA_VT_ROW = 68;   // halves per padded V^T row (64 keys + 4), fp32-source path
 constexpr size_t FA_WS_SKIP = 16384;  // head of the workspace left alone (decode arrival tickets)
 
@@ -168,24 +171,28 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
 
   // ---- LDS-DMA roles: piece p = wave + NW i of a tile; pieces 0..DK_PIECES-1 are K rows, the
   //      rest V^T rows; lane l fills bytes 16 l .. 16 l + 15 of the piece ----
-  const _Float16* dsrc[DPER];
-  int dstep[DPER];  // halves from one tile to the next
+  // per piece: a wave-uniform base (the kv head's K or V^T image) and this lane's byte offset, which
+  // moves on by a wave-uniform step from one tile to the next
+  const char* dbase[DPER];
+  unsigned doff[DPER], dstep[DPER];
   if constexpr (DMA) {
-    const _Float16* k16base = a.k16 + (size_t)kvh * a.s_pad * HS;
-    const _Float16* v16base = a.v16t + (size_t)kvh * HS * a.s_pad;
+    const char* k16base = reinterpret_cast<const char*>(a.k16 + (size_t)kvh * a.s_pad * HS);
+    const char* v16base = reinterpret_cast<const char*>(a.v16t + (size_t)kvh * HS * a.s_pad);
 #pragma unroll
     for (int i = 0; i < DPER; ++i) {
       const int p = wave % NW + NW * i;
       if (p < DK_PIECES) {
         const int row = p * (1024 / DK_ROWB) + lane / DKCH, pos = lane % DKCH;
         const int chunk = pos ^ ((row * DKCH / 16) % DKCH);
-        dsrc[i] = k16base + (size_t)row * HS + 8 * chunk;
-        dstep[i] = FA_KV * HS;
+        dbase[i] = k16base;
+        doff[i] = (unsigned)(row * DK_ROWB + 16 * chunk);
+        dstep[i] = FA_KV * DK_ROWB;
       } else {
         const int d = (p - DK_PIECES) * 8 + (lane >> 3), pos = lane & 7;
         const int chunk = pos ^ ((d >> 1) & 7);
-        dsrc[i] = v16base + (size_t)d * a.s_pad + 8 * chunk;
-        dstep[i] = FA_KV;
+        dbase[i] = v16base;
+        doff[i] = (unsigned)(d * a.s_pad * 2 + 16 * chunk);
+        dstep[i] = FA_KV * 2;
       }
     }
   }
@@ -193,11 +200,15 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     if (wave >= NW) return;  // workgroups of 5..7 waves: the first four bring the tiles in
 #pragma unroll
     for (int i = 0; i < DPER; ++i)
-      __builtin_amdgcn_global_load_lds(dsrc[i] + (size_t)t * dstep[i],
+      __builtin_amdgcn_global_load_lds(dbase[i] + (doff[i] + (unsigned)t * dstep[i]),
                                        (lds_ptr_t)(smem + buf * DBUF_B + (wave + NW * i) * 1024), 16, 0,
                                        0);
   };
-  if constexpr (DMA) issue_tile(0, 0);
+  if constexpr (DMA) {
+#pragma unroll
+    for (int j = 0; j < FA_TPB; ++j)
+      if (j < ntiles) issue_tile(j, j);
+  }
 
   // ---- Q fragment (B operand): lane (q row, half) holds Q[row][16ks + 8half + j] * scale ----
   // scores are kept in the log2 domain: Q is scaled by softmax_scale * log2(e)
@@ -330,13 +341,7 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
   // tiles past this wave's own last query row contribute nothing to it
   const int wave_last_pos = a.causal ? min(qpos0 + min(q0 + 31, a.Tq - 1), a.pos) : a.pos;
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    FA_STAMP(0);
-    if (t + 1 < ntiles) {
-      if constexpr (DMA) issue_tile(t + 1, buf ^ 1); else load_tile(t + 1);
-    }
-    FA_STAMP(1);
+  auto compute_tile = [&](int t, int buf) {
     const int key0 = t * FA_KV;
     if (key0 <= wave_last_pos) {
       const _Float16* Kl = lds + buf * BUF;
@@ -344,16 +349,53 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
       const char* Dl = smem + buf * DBUF_B;
       // ---- S^T[key][q] for the tile's two 32-key halves ----
       f32x16 s[2];
+      f16x8 vf[2][DT];  // V^T fragments of two 16-key steps (DMA form)
+      if constexpr (DMA) {
+        // fragments are requested a stage ahead of the MFMAs that use them (read, then multiplied
+        // at once, every pair of MFMAs waited a full LDS round trip): the first key half's all
+        // at once, the second half's and the first V^T step's under the first half's MFMAs
+        constexpr int KH = KS / 2;
+        f16x8 ka[KS], kb[KS];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+        for (int ks = 0; ks < KS; ++ks)
+          ka[ks] = *reinterpret_cast<const f16x8*>(Dl + koff[ks]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-        const _Float16* kp = Kl + (kt * 32 + qcol) * K_ROW + 8 * half;
+        for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const f16x8 kf = DMA ? *reinterpret_cast<const f16x8*>(Dl + kt * 32 * DK_ROWB + koff[ks])
-                               : *reinterpret_cast<const f16x8*>(kp + 16 * ks);
-          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+        for (int ks = 0; ks < KH; ++ks)
+          kb[ks] = *reinterpret_cast<const f16x8*>(Dl + 32 * DK_ROWB + koff[ks]);
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks)
+          s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[ks], s[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = KH; ks < KS; ++ks)
+          kb[ks] = *reinterpret_cast<const f16x8*>(Dl + 32 * DK_ROWB + koff[ks]);
+#pragma unroll
+        for (int ks = KH; ks < KS; ++ks)
+          s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[ks], s[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[1][r] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          vf[0][dt] = *reinterpret_cast<const f16x8*>(Dl + dt * 32 * 128 + voff[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb[ks], qf[ks], s[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+          const _Float16* kp = Kl + (kt * 32 + qcol) * K_ROW + 8 * half;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + 16 * ks);
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+          }
         }
       }
       FA_STAMP(2);
@@ -397,55 +439,100 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
       FA_STAMP(3);
       const float m_use = m_run == -INFINITY ? 0.f : m_run;
       float psum = 0.f;
+      if constexpr (DMA) {
+        // ---- O^T[d][q] += V^T . P^T in four 16-key steps g = 2kt + st; registers 8st..8st+7 of
+        //      score tile kt are the B fragment of the step, element j <-> key 16st + 8(j>>2) +
+        //      4half + (j&3), the order the V^T image keeps its keys in.  Step g's MFMAs run beside
+        //      the exponentials of step g+1 and the V^T reads of step g+1 ----
+        auto probs = [&](int g, f16x8& pf) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+          for (int j = 0; j < 8; ++j) {
+            // raw v_exp_f32: the argument is <= kLazy, and a result below 2^-126 may flush to zero
+            const float p = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + j] - m_use);
+            psum += p;
+            pf[j] = (_Float16)p;
+          }
+        };
+        f16x8 pf[2];
+        probs(0, pf[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // raw v_exp_f32: the argument is <= kLazy, and a result below 2^-126 may flush to zero
-          const float p = __builtin_amdgcn_exp2f(s[kt][r] - m_use);
-          s[kt][r] = p;
-          psum += p;
+        for (int g = 0; g < 4; ++g) {
+          if (g + 1 < 4) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+              vf[(g + 1) & 1][dt] =
+                  *reinterpret_cast<const f16x8*>(Dl + dt * 32 * 128 + voff[g + 1]);
+          }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g & 1][dt], pf[g & 1], o[dt], 0, 0, 0);
+          if (g + 1 < 4) probs(g + 1, pf[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      l_run += psum;
-      // ---- O^T[d][q] += V^T . P^T ; registers 8s..8s+7 of a score tile are the B fragment of
-      //      16-key step s, element j <-> key 16s + 8(j>>2) + 4half + (j&3) ----
+        l_run += psum;
+      } else {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          f16x8 pf;
+          for (int r = 0; r < 16; ++r) {
+            // raw v_exp_f32: the argument is <= kLazy, and a result below 2^-126 may flush to zero
+            const float p = __builtin_amdgcn_exp2f(s[kt][r] - m_use);
+            s[kt][r] = p;
+            psum += p;
+          }
+        l_run += psum;
+        // ---- O^T[d][q] += V^T . P^T ; registers 8s..8s+7 of a score tile are the B fragment of
+        //      16-key step s, element j <-> key 16s + 8(j>>2) + 4half + (j&3) ----
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = (_Float16)s[kt][8 * st + j];
-          if constexpr (DMA) {
-            // keys are stored in score-register order: the fragment is one 16-byte read
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-              const f16x8 vf = *reinterpret_cast<const f16x8*>(Dl + dt * 32 * 128 + voff[2 * kt + st]);
-              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
-            }
-          } else {
+          for (int st = 0; st < 2; ++st) {
+            f16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (_Float16)s[kt][8 * st + j];
             const _Float16* vp = Vl + qcol * VT_ROW + kt * 32 + 16 * st + 4 * half;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
               const f16x4 lo = *reinterpret_cast<const f16x4*>(vp + dt * 32 * VT_ROW);
               const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + dt * 32 * VT_ROW + 8);
-              f16x8 vf;
-              vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-              vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+              f16x8 vfr;
+              vfr[0] = lo[0]; vfr[1] = lo[1]; vfr[2] = lo[2]; vfr[3] = lo[3];
+              vfr[4] = hi[0]; vfr[5] = hi[1]; vfr[6] = hi[2]; vfr[7] = hi[3];
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr, pf, o[dt], 0, 0, 0);
             }
           }
-        }
+      }
     }
-    FA_STAMP(4);
-    if constexpr (DMA) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile are in
-    } else {
+  };
+
+  if constexpr (DMA) {
+    // FA_TPB tiles per barrier interval in a ring of 2 FA_TPB buffers: the waves meet half as
+    // often, and between two meetings they drift apart, so the two waves of a SIMD are less often
+    // in the same phase (both reading LDS right after the barrier, both in their MFMAs)
+    for (int t0 = 0; t0 < ntiles; t0 += FA_TPB) {
+      FA_STAMP(0);
+#pragma unroll
+      for (int j = 0; j < FA_TPB; ++j)
+        if (t0 + FA_TPB + j < ntiles) issue_tile(t0 + FA_TPB + j, (t0 + FA_TPB + j) % (2 * FA_TPB));
+      FA_STAMP(1);
+#pragma unroll
+      for (int j = 0; j < FA_TPB; ++j)
+        if (t0 + j < ntiles) compute_tile(t0 + j, (t0 + j) % (2 * FA_TPB));
+      FA_STAMP(4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tiles are in
+      FA_STAMP(5);
+      __syncthreads();
+      FA_STAMP(6);
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < ntiles) load_tile(t + 1);
+      compute_tile(t, buf);
       if (t + 1 < ntiles) store_tile(buf ^ 1);
+      __syncthreads();
     }
-    FA_STAMP(5);
-    __syncthreads();
-    FA_STAMP(6);
   }
 #ifdef FA_TRACE
   if (traced && lane == 0) {
@@ -486,7 +573,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
 
 template <int HS, bool DMA, int NW>
 static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
-  constexpr size_t lds = DMA ? 2 * (size_t)(2 * FA_KV * HS * 2)
+  constexpr size_t lds = DMA ? 2 * FA_TPB * (size_t)(2 * FA_KV * HS * 2)
                              : 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
   static OncePerDevice raised;
   if (lds > 64 * 1024 && raised.first())
@@ -589,7 +676,10 @@ static int flash_attention_run(const float* query, const void* key_cache_any,
   // eight-wave form wins (32 heads x 4096 rows: 186 vs 197 us).
   {
     const int qblocks8 = (Tq + 32 * qsubs - 1) / (32 * qsubs);
-    if ((long)kv_head_num * (kv_mul / hpb) * qblocks8 < 512 && hpb * qsubs > 4) {
+#ifndef FA_FOUR_WAVE_BELOW
+#define FA_FOUR_WAVE_BELOW 512
+#endif
+    if ((long)kv_head_num * (kv_mul / hpb) * qblocks8 < FA_FOUR_WAVE_BELOW && hpb * qsubs > 4) {
       int h4 = 1;
       for (int d = 1; d <= 4 && d <= kv_mul; ++d)
         if (kv_mul % d == 0) h4 = d;
