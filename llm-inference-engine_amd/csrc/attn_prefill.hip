@@ -22,14 +22,13 @@
 //     copies; without it each workgroup converts the fp32 rows it stages.
 #include <math.h>
 
+#include <type_traits>
+
 #include "kx_common.hpp"
 
 namespace kx {
 
 constexpr int FA_KV = 64;       // keys per tile
-#ifndef FA_TPB
-#define FA_TPB 1                // tiles per barrier interval (LDS-DMA form)
-#endif
 constexpr int FA_VT_ROW = 68;   // halves per padded V^T row (64 keys + 4), fp32-source path
 constexpr size_t FA_WS_SKIP = 16384;  // head of the workspace left alone (decode arrival tickets)
 
@@ -147,6 +146,9 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
   using lds_ptr_t = __attribute__((address_space(3))) void*;
   _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
+#ifdef FA_TRACE
+  const unsigned long long tr_start = __builtin_readcyclecounter();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x;
@@ -204,11 +206,7 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
                                        (lds_ptr_t)(smem + buf * DBUF_B + (wave + NW * i) * 1024), 16, 0,
                                        0);
   };
-  if constexpr (DMA) {
-#pragma unroll
-    for (int j = 0; j < FA_TPB; ++j)
-      if (j < ntiles) issue_tile(j, j);
-  }
+  if constexpr (DMA) issue_tile(0, 0);
 
   // ---- Q fragment (B operand): lane (q row, half) holds Q[row][16ks + 8half + j] * scale ----
   // scores are kept in the log2 domain: Q is scaled by softmax_scale * log2(e)
@@ -507,23 +505,25 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
   };
 
   if constexpr (DMA) {
-    // FA_TPB tiles per barrier interval in a ring of 2 FA_TPB buffers: the waves meet half as
-    // often, and between two meetings they drift apart, so the two waves of a SIMD are less often
-    // in the same phase (both reading LDS right after the barrier, both in their MFMAs)
-    for (int t0 = 0; t0 < ntiles; t0 += FA_TPB) {
+    // two buffers, one barrier per tile: the pieces of tile t+1 are requested at the top of
+    // interval t, into the buffer whose tile every wave left behind at the last barrier.  The loop
+    // is written out for a pair of tiles so that the buffer is a compile-time constant and every
+    // fragment address is a register plus an immediate.
+    auto interval = [&](int t, auto buf_c) {
+      constexpr int buf = decltype(buf_c)::value;
       FA_STAMP(0);
-#pragma unroll
-      for (int j = 0; j < FA_TPB; ++j)
-        if (t0 + FA_TPB + j < ntiles) issue_tile(t0 + FA_TPB + j, (t0 + FA_TPB + j) % (2 * FA_TPB));
+      if (t + 1 < ntiles) issue_tile(t + 1, buf ^ 1);
       FA_STAMP(1);
-#pragma unroll
-      for (int j = 0; j < FA_TPB; ++j)
-        if (t0 + j < ntiles) compute_tile(t0 + j, (t0 + j) % (2 * FA_TPB));
+      compute_tile(t, buf);
       FA_STAMP(4);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tiles are in
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile are in
       FA_STAMP(5);
       __syncthreads();
       FA_STAMP(6);
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+      interval(t, std::integral_constant<int, 0>{});
+      if (t + 1 < ntiles) interval(t + 1, std::integral_constant<int, 1>{});
     }
   } else {
     for (int t = 0; t < ntiles; ++t) {
@@ -540,7 +540,9 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     fa_trace_buf[wave][8] = __builtin_readcyclecounter() - tr_c0;
     fa_trace_buf[wave][9] = __builtin_amdgcn_s_memrealtime() - tr_r0;
     fa_trace_buf[wave][10] = ntiles;
+    fa_trace_buf[wave][11] = tr_c0 - tr_start;
   }
+  const unsigned long long tr_loop_end = __builtin_readcyclecounter();
 #endif
 
   // ---- epilogue: lane (q row, half) holds O[row][32dt + 8g + 4half + e] in o[dt][4g+e] ----
@@ -563,6 +565,10 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
         }
       }
   }
+#ifdef FA_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (traced && lane == 0) fa_trace_buf[wave][12] = __builtin_readcyclecounter() - tr_loop_end;
+#endif
 }
 
 // the body lives in a device-only function: the host pass then never instantiates its LDS-DMA calls
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
 
 template <int HS, bool DMA, int NW>
 static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
-  constexpr size_t lds = DMA ? 2 * FA_TPB * (size_t)(2 * FA_KV * HS * 2)
+  constexpr size_t lds = DMA ? 2 * (size_t)(2 * FA_KV * HS * 2)
                              : 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
   static OncePerDevice raised;
   if (lds > 64 * 1024 && raised.first())
@@ -676,10 +682,10 @@ static int flash_attention_run(const float* query, const void* key_cache_any,
   // eight-wave form wins (32 heads x 4096 rows: 186 vs 197 us).
   {
     const int qblocks8 = (Tq + 32 * qsubs - 1) / (32 * qsubs);
-#ifndef FA_FOUR_WAVE_BELOW
-#define FA_FOUR_WAVE_BELOW 512
-#endif
-    if ((long)kv_head_num * (kv_mul / hpb) * qblocks8 < FA_FOUR_WAVE_BELOW && hpb * qsubs > 4) {
+    // Heads of at most 64 dims need half the registers: four four-wave workgroups fit a CU and
+    // overlap each other's prologues and epilogues (32 heads x 64 x 4096 rows: 110 -> 101 us).
+    const bool small_grid = (long)kv_head_num * (kv_mul / hpb) * qblocks8 < 512;
+    if ((small_grid || head_size <= 64) && hpb * qsubs > 4) {
       int h4 = 1;
       for (int d = 1; d <= 4 && d <= kv_mul; ++d)
         if (kv_mul % d == 0) h4 = d;

@@ -27,4 +27,5 @@ print(f"{us:.1f} us per launch; tiles {int(a[0,10])}")
 for w in range(8):
     nt = a[w, 10]
     print(f"wave {w}: " + "  ".join(f"{n} {a[w,i]/nt:.0f}" for i, n in enumerate(names)) +
-          f"  | per tile {a[w,8]/nt:.0f} cyc, clock {a[w,8]/a[w,9]/10:.2f} GHz")
+          f"  | per tile {a[w,8]/nt:.0f} cyc, clock {a[w,8]/a[w,9]/10:.2f} GHz"
+          f"  | prologue {a[w,11]:.0f} cyc, epilogue (stores acknowledged) {a[w,12]:.0f} cyc")
