@@ -117,6 +117,56 @@ __device__ __forceinline__ float fa_halves_max(float v) {
   return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 
+// A wave's 32 x HS output tile leaves through LDS: the accumulators hold "lane = query row", so
+// direct stores put 16 bytes per lane at a row stride (64 row segments per instruction, every
+// 128-byte line written by four instructions); turned around in the wave's own LDS region, an
+// instruction stores whole row segments of up to 256 bytes.  Rounds of SEG bytes per row; 16-byte
+// chunk c of a row sits at chunk position c ^ key(row) (the K image's rule), so the reads of 16
+// consecutive lanes -- one row segment, or two -- cover the banks once.
+template <int HS, typename OutT>
+__device__ __forceinline__ void fa_store_rows(char* region, const f32x16 (&o)[HS / 32], float inv,
+                                              OutT* out_row0, size_t row_stride, int rows_valid,
+                                              int lane) {
+  constexpr int ES = sizeof(OutT);
+  constexpr int SEG = HS * ES < 256 ? HS * ES : 256;  // bytes per row and round
+  constexpr int C = SEG / 16;                          // chunks per row segment
+  constexpr int ROUNDS = HS * ES / SEG;
+  constexpr int DT_PER_ROUND = (HS / 32) / ROUNDS;
+  constexpr int RPI = 64 / C;                          // rows per store instruction
+  const int qcol = lane & 31, half = lane >> 5;
+  const int wkey = (qcol * C / 16) % C;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+    for (int dtl = 0; dtl < DT_PER_ROUND; ++dtl)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dt = r * DT_PER_ROUND + dtl;
+        const f32x4 v = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                         o[dt][4 * g + 3] * inv};
+        if constexpr (ES == 4) {
+          const int chunk = 8 * dtl + 2 * g + half;
+          *reinterpret_cast<f32x4*>(region + qcol * SEG + ((chunk ^ wkey) << 4)) = v;
+        } else {
+          const int chunk = 4 * dtl + g;
+          f16x4 h;
+          h[0] = sat_f16(v.x); h[1] = sat_f16(v.y); h[2] = sat_f16(v.z); h[3] = sat_f16(v.w);
+          *reinterpret_cast<f16x4*>(region + qcol * SEG + ((chunk ^ wkey) << 4) + 8 * half) = h;
+        }
+      }
+    // the wave reads back what its own lanes wrote: LDS serves a wave's instructions in order
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const int row = lane / C + RPI * j, c = lane % C;
+      const int rkey = (row * C / 16) % C;
+      const i32x4 val = *reinterpret_cast<const i32x4*>(region + row * SEG + ((c ^ rkey) << 4));
+      if (row < rows_valid)
+        *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(out_row0 + (size_t)row * row_stride) +
+                                  r * SEG + c * 16) = val;
+    }
+  }
+}
+
 // DMA: the K/V tiles come from the fp16 copies by LDS-DMA (global_load_lds: 1 KiB per wave
 // instruction straight into LDS, no staging registers, no ds_write pass; the first NW waves of
 // the workgroup bring in 1/NW of a tile's pieces each).  An instruction fills LDS linearly, so rows cannot
@@ -211,18 +261,22 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
   // ---- Q fragment (B operand): lane (q row, half) holds Q[row][16ks + 8half + j] * scale ----
   // scores are kept in the log2 domain: Q is scaled by softmax_scale * log2(e)
   constexpr float kLog2e = 1.4426950408889634f;
-  const float qscale = a.scale * kLog2e;
+  const float qscale_all = a.scale * kLog2e;
   f16x8 qf[KS];
   {
-    const bool valid = my_row < a.Tq;
+    // rows past the end re-read the last row and scale it by zero, so all the loads are requested
+    // at once (under a lane test hipcc branches around each pair and waits inside some branches)
     const float* qp = a.q + ((size_t)min(my_row, a.Tq - 1) * a.H + head) * HS + 8 * half;
+    f32x4 qraw[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
-        v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
-        v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
-      }
+      qraw[ks][0] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+      qraw[ks][1] = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+    }
+    const float qscale = my_row < a.Tq ? qscale_all : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 v0 = qraw[ks][0], v1 = qraw[ks][1];
       qf[ks][0] = (_Float16)(v0.x * qscale);
       qf[ks][1] = (_Float16)(v0.y * qscale);
       qf[ks][2] = (_Float16)(v0.z * qscale);
@@ -547,8 +601,30 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
 
   // ---- epilogue: lane (q row, half) holds O[row][32dt + 8g + 4half + e] in o[dt][4g+e] ----
   l_run += lane_xor32(l_run);
-  if (my_row < a.Tq) {
-    const float inv = 1.0f / l_run;
+  const float inv = 1.0f / l_run;
+  bool stored = false;
+  if constexpr (DMA) {
+    // every wave is past the last tile's barrier: the tile buffers are free
+    const int nwaves = nthreads >> 6;
+    const size_t head_off = ((size_t)q0 * a.H + head) * HS;
+    const int rows_valid = a.Tq - q0;  // <= 0: a wave whose rows are all past the end
+    if (a.out16) {
+      constexpr int RB = 32 * (HS * 2 < 256 ? HS * 2 : 256);
+      if (nwaves * RB <= 2 * DBUF_B) {
+        fa_store_rows<HS, _Float16>(smem + wave * RB, o, inv, a.out16 + head_off, (size_t)a.H * HS,
+                                    rows_valid, lane);
+        stored = true;
+      }
+    } else {
+      constexpr int RB = 32 * (HS * 4 < 256 ? HS * 4 : 256);
+      if (nwaves * RB <= 2 * DBUF_B) {
+        fa_store_rows<HS, float>(smem + wave * RB, o, inv, a.out + head_off, (size_t)a.H * HS, rows_valid,
+                                 lane);
+        stored = true;
+      }
+    }
+  }
+  if (!stored && my_row < a.Tq) {
     const size_t off = ((size_t)my_row * a.H + head) * HS + 4 * half;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)

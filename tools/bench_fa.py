@@ -15,7 +15,7 @@ for buf, n, seed in ((q, T * H * hs, 3), (kc, T * kvd, 4), (vc, T * kvd, 5)):
 wsb = max(L.kx_attn_workspace_bytes(H, hs), L.kx_flash_attention_workspace_bytes(T - 1, KVH, hs))
 ws = kx.Buf.zeros(wsb, np.uint8)
 def fa():
-    kx.check(L.kx_flash_attention_f32(q.ptr, kc.ptr, vc.ptr, out.ptr, T, H, KVH, hs, T, T - 1, 0, float(1 / np.sqrt(hs)), 1, ws.ptr, wsb, st.ptr))
+    kx.check(L.kx_flash_attention_f16out(q.ptr, kc.ptr, vc.ptr, out.ptr, T, H, KVH, hs, T, T - 1, 0, float(1 / np.sqrt(hs)), 1, ws.ptr, wsb, st.ptr) if os.environ.get("FA_F16OUT") else L.kx_flash_attention_f32(q.ptr, kc.ptr, vc.ptr, out.ptr, T, H, KVH, hs, T, T - 1, 0, float(1 / np.sqrt(hs)), 1, ws.ptr, wsb, st.ptr))
 us = min(kx.time_graph(st, fa, replays=10) for _ in range(3))
 o = out.numpy(np.float32, (T * H * hs,))
 print(os.path.basename(os.environ.get("KX_HIP_LIB", "default")), f"{us:.1f} us  {4.0*hs*T*(T+1)/2*H/us*1e-6:.0f} TF  chk {float(np.nansum(np.abs(o[:100000]))):.4e}", flush=True)
