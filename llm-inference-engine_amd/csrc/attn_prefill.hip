@@ -9,17 +9,21 @@
 //   - one workgroup = one kv head x a block of query rows for ALL the query heads that share the
 //     kv head (wave w -> head w % HPB, 32-row sub-block w / HPB), so a staged K/V tile feeds
 //     kv_mul times more MFMA work than it would per head.
-//   - K/V tiles of 64 keys are read from the fp32 cache, rounded to fp16 and staged in LDS
-//     (K row-major, V transposed), two buffers, one barrier per tile; the next tile's global
-//     loads are issued before the current tile's MFMAs.
+//   - with a workspace of kx_flash_attention_workspace_bytes() the layer's K/V rows are converted
+//     to fp16 once per call (K row-major, V transposed with its keys in score-register order);
+//     tiles of 64 keys then come in by LDS-DMA into XOR-swizzled unpadded images, two buffers,
+//     one barrier per tile, the next tile requested at the top of the current one.  Without a
+//     workspace (or for caches of at most three tiles) each workgroup rounds the fp32 rows it
+//     stages on their way through registers into padded images.
 //   - S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_f16.  With the key index on the
 //     register axis and the query row on the lane, the exponentiated score registers are already
 //     the B operand of the second product: probabilities never leave registers, and the
 //     online-softmax state (running max, running sum, rescale factor) is one value per lane.
+//   - LDS fragments are requested a stage ahead of the MFMAs that use them, and the exponentials
+//     of one 16-key step run beside the MFMAs of the step before (scheduling fences between the
+//     stages keep hipcc from pulling the reads back next to their uses).
 //   - fp32 everywhere outside the two MFMA operand roundings (Q*scale, K, V, P to fp16).
-//   - with a workspace of kx_flash_attention_workspace_bytes() the layer's K/V rows are converted
-//     to fp16 once per call (K row-major, V transposed) and the tiles are staged by 16-byte
-//     copies; without it each workgroup converts the fp32 rows it stages.
+//   - the output tile leaves through LDS as whole row segments (fa_store_rows).
 #include <math.h>
 
 #include <type_traits>
@@ -168,15 +172,18 @@ __device__ __forceinline__ void fa_store_rows(char* region, const f32x16 (&o)[HS
 }
 
 // DMA: the K/V tiles come from the fp16 copies by LDS-DMA (global_load_lds: 1 KiB per wave
-// instruction straight into LDS, no staging registers, no ds_write pass; the first NW waves of
-// the workgroup bring in 1/NW of a tile's pieces each).  An instruction fills LDS linearly, so rows cannot
+// instruction straight into LDS, no staging registers, no ds_write pass; waves 0..3 of the
+// workgroup bring in a quarter of a tile's pieces each: in an eight-wave workgroup they are the
+// waves that otherwise wait at the barrier for their SIMD partners, and who issues made no
+// difference to the time).  An instruction fills LDS linearly, so rows cannot
 // be padded: 16-byte chunk c of a row sits at chunk position c ^ key(row) instead -- applied to the
 // SOURCE address when filling and to the LDS address when reading -- with the key chosen so that
 // the 16 rows read by 16 consecutive lanes cover all 64 banks.
 // !DMA: the fp32 cache rows are rounded to fp16 on their way through registers into padded images
 // (no workspace, or a cache of at most three tiles).
-template <int HS, bool DMA, int NW>
+template <int HS, bool DMA>
 __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
+  constexpr int NW = 4;                 // waves that issue the LDS-DMA pieces
   constexpr int K_ROW = HS + 8;         // halves per padded K row (!DMA)
   constexpr int KS = HS / 16;           // 16-dim MFMA steps of Q.K
   constexpr int DT = HS / 32;           // 32-dim output tiles
@@ -249,7 +256,7 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     }
   }
   auto issue_tile = [&](int t, int buf) {
-    if (wave >= NW) return;  // workgroups of 5..7 waves: the first four bring the tiles in
+    if (wave >= NW) return;
 #pragma unroll
     for (int i = 0; i < DPER; ++i)
       __builtin_amdgcn_global_load_lds(dbase[i] + (doff[i] + (unsigned)t * dstep[i]),
@@ -648,21 +655,21 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
 }
 
 // the body lives in a device-only function: the host pass then never instantiates its LDS-DMA calls
-template <int HS, bool DMA, int NW>
+template <int HS, bool DMA>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(const FaArgs a) {
-  attn_prefill_body<HS, DMA, NW>(a);
+  attn_prefill_body<HS, DMA>(a);
 }
 
-template <int HS, bool DMA, int NW>
+template <int HS, bool DMA>
 static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblocks, hipStream_t s) {
   constexpr size_t lds = DMA ? 2 * (size_t)(2 * FA_KV * HS * 2)
                              : 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
   static OncePerDevice raised;
   if (lds > 64 * 1024 && raised.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, DMA, NW>),
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, DMA>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid(kvh * (a.kv_mul / a.hpb), qblocks);
-  hipLaunchKernelGGL((attn_prefill_kernel<HS, DMA, NW>), grid, dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((attn_prefill_kernel<HS, DMA>), grid, dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -689,10 +696,9 @@ static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* wor
     a.k16 = k16;
     a.v16t = v16t;
     a.s_pad = s_pad;
-    if (threads == 512) return launch_prefill_kernel<HS, true, 8>(a, kvh, threads, qblocks, s);
-    return launch_prefill_kernel<HS, true, 4>(a, kvh, threads, qblocks, s);
+    return launch_prefill_kernel<HS, true>(a, kvh, threads, qblocks, s);
   }
-  return launch_prefill_kernel<HS, false, 8>(a, kvh, threads, qblocks, s);
+  return launch_prefill_kernel<HS, false>(a, kvh, threads, qblocks, s);
 }
 
 }  // namespace kx
