@@ -447,6 +447,27 @@ int kx_comm_broadcast_f32(void* comm, const float* sendbuf, float* recvbuf, size
 int kx_comm_allgather_f32(void* comm, const float* sendbuf, float* recvbuf, size_t send_count,
                           void* stream);
 
+/* ---------------- peer mailboxes: one-launch collectives for the token loop ----------------
+ * The reference's only collective is NcclHandler::AllReduce (kuiper/source/base/nccl_handler.cpp:
+ * 84-117), called behind every row-parallel matmul (kuiper/source/op/matmul.cpp:93-116).  These
+ * entries carry the same sum for vectors of up to max_floats (a token's `dim` floats) in ONE kernel
+ * on the caller's stream: every rank owns a mailbox in fine-grained device memory that the other
+ * ranks of the node map through a 64-byte IPC handle; the kernel writes its vector into every
+ * mailbox, publishes a sequence number behind it, waits for the other ranks' numbers and adds the
+ * slots in rank order (bitwise the same sum on every rank).  Graph-capturable.  Set-up:
+ * kx_peer_create on every rank, exchange the kx_peer_handle bytes, kx_peer_connect with all of
+ * them ordered by rank, then a host-side barrier before the first collective.  A wait that gives
+ * up after 4 s finishes the launch and raises the flag kx_peer_timed_out reads. */
+int kx_peer_create(void** group, int32_t world_size, int32_t rank, size_t max_floats);
+int kx_peer_handle(void* group, void* handle64);
+int kx_peer_connect(void* group, const void* handles);
+/* in place; count <= max_floats (KX_ELIMIT beyond), buf 16-byte aligned */
+int kx_peer_allreduce_sum_f32(void* group, float* buf, size_t count, void* stream);
+/* buf holds world_size x count_per_rank floats, this rank's part already in place */
+int kx_peer_allgather_f32(void* group, float* buf, size_t count_per_rank, void* stream);
+int kx_peer_timed_out(void* group, int32_t* flag);
+int kx_peer_destroy(void* group);
+
 #ifdef __cplusplus
 }
 #endif

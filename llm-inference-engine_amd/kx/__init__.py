@@ -132,6 +132,13 @@ SIGNATURES = {
     "kx_comm_allreduce_sum_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "kx_comm_broadcast_f32": (C.c_int, [_vp, _vp, _vp, _sz, _i32, _vp]),
     "kx_comm_allgather_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "kx_peer_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _sz]),
+    "kx_peer_handle": (C.c_int, [_vp, _vp]),
+    "kx_peer_connect": (C.c_int, [_vp, _vp]),
+    "kx_peer_allreduce_sum_f32": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "kx_peer_allgather_f32": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "kx_peer_timed_out": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "kx_peer_destroy": (C.c_int, [_vp]),
 }
 
 

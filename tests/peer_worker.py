@@ -1,0 +1,101 @@
+"""One rank of the peer-mailbox collectives test (tests/test_gpu_peer.py starts world_size of
+these as separate processes, all on GPU 0, so the mailboxes really are mapped across processes
+through IPC handles).  Ranks meet over gloo on 127.0.0.1 to exchange the 64-byte handles.
+Prints one JSON line; exit status 0 only when every check of this rank passed."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
+
+
+def main():
+    rank, world, port, count = (int(v) for v in sys.argv[1:5])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import kx
+    L = kx.lib()
+    kx.check(L.kx_set_device(0), "set_device")
+    st = kx.Stream()
+    g = C.c_void_p()
+    kx.check(L.kx_peer_create(C.byref(g), world, rank, count), "peer_create")
+    h = C.create_string_buffer(64)
+    kx.check(L.kx_peer_handle(g, h), "peer_handle")
+    handles = [None] * world
+    dist.all_gather_object(handles, h.raw)
+    kx.check(L.kx_peer_connect(g, C.create_string_buffer(b"".join(handles), 64 * world)), "peer_connect")
+    dist.barrier()  # every mailbox is zeroed and mapped before anybody writes
+
+    def vec(r, it, n):
+        return np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float32)
+
+    def expect_sum(it, n):
+        acc = vec(0, it, n).copy()
+        for r in range(1, world):
+            acc = acc + vec(r, it, n)  # rank order, fp32: what the kernel does
+        return acc
+
+    ok = True
+    worst = 0.0
+    # eager calls, alternating sizes (both parities of the slot pair, odd tails)
+    sizes = [count, 4096 if count >= 4096 else count, 1000, 6, count]
+    for it, n in enumerate(sizes):
+        n = min(n, count)
+        buf = kx.Buf.from_numpy(np.concatenate([vec(rank, it, n), np.zeros(4, np.float32)]))
+        kx.check(L.kx_peer_allreduce_sum_f32(g, buf.ptr, n, st.ptr), "peer_allreduce")
+        st.sync()
+        got = buf.numpy(np.float32, (n + 4,))
+        want = expect_sum(it, n)
+        ok &= bool(np.array_equal(got[:n], want)) and bool(np.all(got[n:] == 0))
+        worst = max(worst, float(np.max(np.abs(got[:n] - want))))
+    # all-gather of two floats per rank (the argmax candidates)
+    parts = np.zeros((world, 2), np.float32)
+    parts[rank] = [rank + 0.5, 100 + rank]
+    gb = kx.Buf.from_numpy(parts)
+    kx.check(L.kx_peer_allgather_f32(g, gb.ptr, 2, st.ptr), "peer_allgather")
+    st.sync()
+    gathered = gb.numpy(np.float32, (world, 2))
+    ok &= bool(np.array_equal(gathered, np.array([[r + 0.5, 100 + r] for r in range(world)], np.float32)))
+    # a captured launch replayed: x <- sum over ranks of x, three times: x0 * world^3 (exact in fp32
+    # for these small integers)
+    n = min(count, 2048)
+    xb = kx.Buf.from_numpy(np.full(n, float(rank + 1), np.float32))
+    gr = C.c_void_p()
+    kx.check(L.kx_graph_begin_capture(st.ptr), "begin_capture")
+    kx.check(L.kx_peer_allreduce_sum_f32(g, xb.ptr, n, st.ptr), "peer_allreduce (captured)")
+    kx.check(L.kx_graph_end_capture(st.ptr, C.byref(gr)), "end_capture")
+    for _ in range(3):
+        kx.check(L.kx_graph_launch(gr, st.ptr), "graph_launch")
+    st.sync()
+    s1 = world * (world + 1) / 2
+    ok &= bool(np.all(xb.numpy(np.float32, (n,)) == np.float32(s1 * world * world)))
+    # timing of back-to-back replays (same-GPU processes: no xGMI in it)
+    e0, e1 = kx.Event(), kx.Event()
+    dist.barrier()
+    e0.record(st.ptr)
+    reps = 50
+    for _ in range(reps):
+        L.kx_graph_launch(gr, st.ptr)
+    e1.record(st.ptr)
+    e1.sync()
+    us = e0.elapsed_ms(e1) * 1e3 / reps
+    flag = C.c_int32(0)
+    kx.check(L.kx_peer_timed_out(g, C.byref(flag)), "peer_timed_out")
+    ok &= flag.value == 0
+    dist.barrier()
+    L.kx_graph_destroy(gr)
+    kx.check(L.kx_peer_destroy(g), "peer_destroy")
+    print(json.dumps({"rank": rank, "ok": bool(ok), "worst_abs_diff": worst, "timed_out": flag.value,
+                      "us_per_allreduce": us}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
