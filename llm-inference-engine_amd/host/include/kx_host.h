@@ -38,6 +38,10 @@ int kxm_shard_plan(int32_t dim, int32_t hidden_dim, int32_t head_num, int32_t kv
                    int32_t tp_size, int32_t tp_rank, int32_t* slices28, int32_t* carries_residual);
 int kxm_comm_unique_id(void* id128);
 int kxm_init_comm(void* model, const void* id128);
+/* peer mailboxes for the token loop's small collectives (LlamaModel::peer_create / peer_connect) */
+int kxm_peer_create(void* model, uint64_t max_floats, void* handle64);
+int kxm_peer_connect(void* model, const void* handles);
+int kxm_peer_timed_out(void* model, int32_t* flag);
 /* Row sub-blocks of the row-parallel prompt GEMMs under tensor parallelism: the all-reduce of one
  * sub-block runs on the side stream beside the GEMM of the next (1 = no overlap; default 4). */
 int kxm_set_prefill_subblocks(void* model, int32_t n);

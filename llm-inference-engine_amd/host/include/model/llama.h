@@ -106,6 +106,13 @@ class LlamaModel {
   base::Status read_weight(const std::string& name, int32_t layer, void* host_out, size_t bytes) const;
 
   base::Status init_comm(const base::CommUniqueId* id);
+  // Peer mailboxes (kx_peer_*): the token loop's reduces and candidate gathers of up to max_floats
+  // floats run as one launch on the compute stream instead of an RCCL call on the side stream;
+  // larger messages (prompt blocks) keep the RCCL path.  peer_create() on every rank, the 64-byte
+  // handles exchanged by the caller, peer_connect() with all of them by rank, a host barrier.
+  base::Status peer_create(size_t max_floats, void* handle64);
+  base::Status peer_connect(const void* handles);
+  base::Status peer_timed_out(bool* flag) const;
   // Test rig: the ranks of a tensor-parallel model as objects of one process (one thread each),
   // summing through a host rendezvous instead of RCCL.  Eager launches only.
   void join_loopback(std::shared_ptr<base::LoopbackGroup> group) { loop_ = std::move(group); }
@@ -189,6 +196,9 @@ class LlamaModel {
   TransformerConfig cfg_;
   bool quant_ = false;
   bool comm_ready_ = false;
+  void* peer_ = nullptr;        // peer-mailbox group; used once connected
+  size_t peer_cap_ = 0;         // floats a peer collective carries at most
+  bool peer_connected_ = false;
   std::shared_ptr<base::LoopbackGroup> loop_;
   std::shared_ptr<kernel::CudaConfig> hip_;
   std::vector<LayerWeights> layers_;

@@ -86,6 +86,16 @@ int kxm_init_comm(void* m, const void* id128) {
   if (id128) std::memcpy(id.data(), id128, id.size());
   return done(M(m)->init_comm(id128 ? &id : nullptr));
 }
+int kxm_peer_create(void* m, uint64_t max_floats, void* handle64) {
+  return done(M(m)->peer_create((size_t)max_floats, handle64));
+}
+int kxm_peer_connect(void* m, const void* handles) { return done(M(m)->peer_connect(handles)); }
+int kxm_peer_timed_out(void* m, int32_t* flag) {
+  bool f = false;
+  const int rc = done(M(m)->peer_timed_out(&f));
+  if (flag) *flag = f ? 1 : 0;
+  return rc;
+}
 int kxm_set_prefill_subblocks(void* m, int32_t n) {
   if (!m) return -1;
   M(m)->set_prefill_subblocks(n);

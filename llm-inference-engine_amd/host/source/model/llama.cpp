@@ -104,6 +104,7 @@ LlamaModel::LlamaModel() = default;
 
 LlamaModel::~LlamaModel() {
   if (graph_) kx_graph_destroy(graph_);
+  if (peer_) kx_peer_destroy(peer_);
   for (auto& l : layers_) {
     free_linear(l.qkv);
     free_linear(l.wo);
@@ -552,6 +553,35 @@ base::Status LlamaModel::init_comm(const base::CommUniqueId* id) {
   return base::error::Success();
 }
 
+base::Status LlamaModel::peer_create(size_t max_floats, void* handle64) {
+  if (peer_) return base::error::InvalidArgument("peer mailboxes already created");
+  if (!handle64 || max_floats == 0) return base::error::InvalidArgument("bad peer mailbox request");
+  KX_RET(kx_peer_create(&peer_, cfg_.tp_size, cfg_.tp_rank, max_floats));
+  peer_cap_ = max_floats;
+  KX_RET(kx_peer_handle(peer_, handle64));
+  return base::error::Success();
+}
+
+base::Status LlamaModel::peer_connect(const void* handles) {
+  if (!peer_ || peer_connected_) return base::error::InvalidArgument("peer_create() first, connect once");
+  KX_RET(kx_peer_connect(peer_, handles));
+  peer_connected_ = true;
+  // a step captured earlier holds the other collective
+  if (graph_) {
+    kx_graph_destroy(graph_);
+    graph_ = nullptr;
+  }
+  return base::error::Success();
+}
+
+base::Status LlamaModel::peer_timed_out(bool* flag) const {
+  if (!peer_ || !flag) return base::error::InvalidArgument("no peer mailboxes");
+  int32_t f = 0;
+  KX_RET(kx_peer_timed_out(peer_, &f));
+  *flag = f != 0;
+  return base::error::Success();
+}
+
 double LlamaModel::linear_weight_bytes_per_token() const {
   if (!quant_) return 0.0;
   double b = 0;
@@ -757,6 +787,10 @@ base::Status LlamaModel::all_reduce(float* buf, size_t count) {
 // collective.  end() makes the compute stream wait for every collective queued since.
 base::Status LlamaModel::all_reduce_begin(float* buf, size_t count) {
   if (loop_) return loop_->all_reduce(cfg_.tp_rank, buf, count, hip_->stream);  // test rig: in line
+  if (peer_connected_ && count <= peer_cap_) {  // one launch on the compute stream; nothing pending
+    KX_RET(kx_peer_allreduce_sum_f32(peer_, buf, count, hip_->stream));
+    return base::error::Success();
+  }
   if (cfg_.tp_size <= 1 && !comm_ready_) return base::error::Success();
   if (!comm_ready_) return base::error::InternalError("tensor-parallel model without init_comm()");
   auto comm = base::RcclHandler::get_instance();
@@ -843,6 +877,10 @@ base::Status LlamaModel::classify_and_pick(const float* x_row, bool write_histor
 
 base::Status LlamaModel::all_gather(float* buf, size_t count) {
   if (loop_) return loop_->all_gather(cfg_.tp_rank, buf, count, hip_->stream);
+  if (peer_connected_ && count <= peer_cap_) {
+    KX_RET(kx_peer_allgather_f32(peer_, buf, count, hip_->stream));
+    return base::error::Success();
+  }
   if (cfg_.tp_size <= 1 && !comm_ready_) return base::error::Success();
   if (!comm_ready_) return base::error::InternalError("tensor-parallel model without init_comm()");
   auto comm = base::RcclHandler::get_instance();
@@ -1230,7 +1268,8 @@ base::Status LlamaModel::sync() const {
 
 base::Status LlamaModel::profile_allreduce(size_t count, int32_t iters, double* ms) {
   if (!ms || iters <= 0 || count == 0) return base::error::InvalidArgument("bad all-reduce profile request");
-  if (!comm_ready_ || loop_) return base::error::InvalidArgument("needs an RCCL communicator");
+  if (!(comm_ready_ || peer_connected_) || loop_)
+    return base::error::InvalidArgument("needs an RCCL communicator or connected peer mailboxes");
   void* st = hip_->stream;
   void* buf = nullptr;
   KX_RET(kx_malloc(&buf, count * sizeof(float)));

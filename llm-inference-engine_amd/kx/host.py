@@ -57,6 +57,9 @@ def hlib():
         L.kxm_read_weight.argtypes = [_vp, C.c_char_p, _i32, _vp, C.c_size_t]
         L.kxm_comm_unique_id.argtypes = [_vp]
         L.kxm_init_comm.argtypes = [_vp, _vp]
+        L.kxm_peer_create.argtypes = [_vp, C.c_uint64, _vp]
+        L.kxm_peer_connect.argtypes = [_vp, _vp]
+        L.kxm_peer_timed_out.argtypes = [_vp, C.POINTER(_i32)]
         L.kxm_forward_layers.argtypes = [_vp, _i32, _i32, _vp]
         L.kxm_set_state.argtypes = [_vp, _i32, _i32]
         L.kxm_step_logits.argtypes = [_vp, _i32, _i32, _vp]
@@ -159,6 +162,22 @@ class Model:
     def init_comm(self, id128: bytes):
         buf = np.frombuffer(id128, np.uint8).copy() if id128 is not None else None
         hcheck(hlib().kxm_init_comm(self.h, _p(buf)), "kxm_init_comm")
+
+    def peer_create(self, max_floats) -> bytes:
+        """Creates this rank's peer mailbox; returns its 64-byte IPC handle for the other ranks."""
+        h = C.create_string_buffer(64)
+        hcheck(hlib().kxm_peer_create(self.h, C.c_uint64(max_floats), h), "kxm_peer_create")
+        return h.raw
+
+    def peer_connect(self, handles):
+        """handles: every rank's handle, ordered by rank.  Follow with a barrier between the ranks."""
+        blob = C.create_string_buffer(b"".join(handles), 64 * len(handles))
+        hcheck(hlib().kxm_peer_connect(self.h, blob), "kxm_peer_connect")
+
+    def peer_timed_out(self) -> bool:
+        f = _i32(0)
+        hcheck(hlib().kxm_peer_timed_out(self.h, C.byref(f)), "kxm_peer_timed_out")
+        return bool(f.value)
 
     def set_prefill_subblocks(self, n):
         L = hlib()

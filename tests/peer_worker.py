@@ -13,12 +13,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
 
 
+TP_SMALL = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
+                rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+
+
+def model_rank(rank, world, dist, out_path):
+    """One tensor-parallel rank of a small model whose collectives all go through the peer
+    mailboxes: ten single steps, a 530-row batched prompt, six greedy steps under graph replay."""
+    import kx
+    from kx import host
+    kx.check(kx.lib().kx_set_device(0), "set_device")
+    seq_len = 576
+    rng = np.random.default_rng(5)
+    toks = rng.integers(0, 700, 10).astype(np.int32)
+    prompt = rng.integers(0, 700, 530).astype(np.int32)
+    m = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, **TP_SMALL)
+    m.init_synthetic(21)
+    handles = [None] * world
+    dist.all_gather_object(handles, m.peer_create(len(prompt) * TP_SMALL["dim"]))
+    m.peer_connect(handles)
+    dist.barrier()
+    steps = np.stack([m.step_logits(int(t), p) for p, t in enumerate(toks)])
+    last = m.prefill(prompt)
+    m.decode(6, use_graph=True)
+    hist = m.history(len(prompt) + 7)
+    timed_out = m.peer_timed_out()
+    dist.barrier()
+    np.savez(out_path, steps=steps, last=last, hist=hist, timed_out=np.array([int(timed_out)]))
+    m.close()
+    print(json.dumps({"rank": rank, "ok": not timed_out, "timed_out": int(timed_out)}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if not timed_out else 1)
+
+
 def main():
     rank, world, port, count = (int(v) for v in sys.argv[1:5])
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if len(sys.argv) > 5 and sys.argv[5] == "model":
+        return model_rank(rank, world, dist, sys.argv[6])
     import kx
     L = kx.lib()
     kx.check(L.kx_set_device(0), "set_device")

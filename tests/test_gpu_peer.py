@@ -7,9 +7,11 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "llm-inference-engine_amd"))
 
 
 def _free_port():
@@ -18,14 +20,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,count", [(2, 4096), (4, 8192), (8, 4096)])
-def test_peer_collectives_across_processes(world, count):
+def _run_ranks(world, count, extra=()):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "peer_worker.py"), str(r), str(world),
-                               str(port), str(count)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                              text=True, env=env) for r in range(world)]
+                               str(port), str(count)] + [str(e).replace("%r", str(r)) for e in extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
     outs = []
     try:
         for p in procs:
@@ -39,3 +40,42 @@ def test_peer_collectives_across_processes(world, count):
         assert rc == 0, f"rank failed (rc {rc}):\n{out}\n{err[-2000:]}"
         rec = json.loads(out.strip().splitlines()[-1])
         assert rec["ok"] and rec["timed_out"] == 0, rec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,count", [(2, 4096), (4, 8192), (8, 4096)])
+def test_peer_collectives_across_processes(world, count):
+    _run_ranks(world, count)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_tensor_parallel_model_across_processes(world, tmp_path):
+    # The tensor-parallel model with one PROCESS per rank (all on this box's one GPU), every
+    # collective of the token loop and of the prompt pass through the peer mailboxes, the greedy
+    # steps under graph replay: all ranks agree bit for bit, and match the unsharded model run here
+    # to the bound of the in-process rig (row-parallel sums are re-associated).
+    import peer_worker
+    from kx import host
+    shape = peer_worker.TP_SMALL
+    rng = np.random.default_rng(5)
+    toks = rng.integers(0, 700, 10).astype(np.int32)
+    prompt = rng.integers(0, 700, 530).astype(np.int32)
+    one = host.Model(seq_len=576, group_size=64, **shape)
+    one.init_synthetic(21)
+    want = np.stack([one.step_logits(int(t), p) for p, t in enumerate(toks)])
+    ref_last = one.prefill(prompt)
+    one.decode(6, use_graph=True)
+    ref_hist = one.history(len(prompt) + 7)
+    one.close()
+    _run_ranks(world, 4096, ("model", str(tmp_path / "rank%r.npz")))
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert int(got[r]["timed_out"][0]) == 0
+        np.testing.assert_array_equal(got[r]["steps"], got[0]["steps"])
+        np.testing.assert_array_equal(got[r]["hist"], got[0]["hist"])
+        assert np.abs(got[r]["last"] - ref_last).max() <= 2e-3 * np.abs(ref_last).max()
+    assert np.abs(got[0]["steps"] - want).max() <= 1e-4 * np.abs(want).max()
+    order = np.argsort(ref_last)
+    if ref_last[order[-1]] - ref_last[order[-2]] > 1e-2 * np.abs(ref_last).max():
+        assert got[0]["hist"][len(prompt)] == ref_hist[len(prompt)]
