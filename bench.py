@@ -393,6 +393,13 @@ def main():
         if not args.no_peer and not args.one_gpu_rehearsal:
             try:
                 connect_peers()
+                # pre-flight: two eager reduces; a rank whose wait gave up (4 s) calls the run off
+                model.profile_allreduce(shape["dim"], 1)
+                t = torch.tensor([float(model.peer_timed_out())], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if t.item() > 0:
+                    model.peer_disable()
+                    raise kx.KxError("peer-mailbox pre-flight: a wait timed out")
                 model.set_state(start_token, start_pos)
                 model.decode(max(args.warmup, 2), use_graph=use_graph)
                 fence()

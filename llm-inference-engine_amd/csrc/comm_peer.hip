@@ -18,7 +18,7 @@
 // The sequence number lives in device memory and is advanced by the kernel, so a launch captured
 // into a HIP graph replays correctly.  Waits are bounded by wall-clock time; a wait that gives up
 // raises a flag the host reads with kx_peer_timed_out() and the launch finishes (with a wrong sum)
-// instead of hanging the queue.
+// instead of hanging the queue; once the flag is up no later call waits at all.
 #include <string.h>
 
 #include "kx_common.hpp"
@@ -60,10 +60,14 @@ template <bool GATHER>
 __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float* buf, int count,
                                                              int world, int rank, size_t cap,
                                                              size_t flags_off) {
-  __shared__ unsigned s_seq;
-  if (threadIdx.x == 0) s_seq = ctx->seq + 1;
+  __shared__ unsigned s_seq, s_dead;
+  if (threadIdx.x == 0) {
+    s_seq = ctx->seq + 1;
+    s_dead = ctx->timed_out;  // a wait gave up earlier: later calls do not wait again
+  }
   __syncthreads();
   const unsigned seq = s_seq, par = seq & 1u;
+  const bool dead = s_dead != 0;
   const float* mine = GATHER ? buf + (size_t)rank * count : buf;
   // 1. this rank's vector into its slot of every mailbox
   const int n4 = count >> 2;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float
     __hip_atomic_store(peer_flag(ctx->box[threadIdx.x], flags_off, par, world, rank), seq,
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   // 3. wait for every rank's number in the own mailbox
-  if ((int)threadIdx.x < world) {
+  if ((int)threadIdx.x < world && !dead) {
     unsigned* f = peer_flag(ctx->box[rank], flags_off, par, world, (int)threadIdx.x);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
@@ -130,10 +134,12 @@ extern "C" int kx_peer_create(void** group, int32_t world_size, int32_t rank, si
   if (!group || world_size < 1 || world_size > kx::kPeerMax || rank < 0 || rank >= world_size ||
       max_floats == 0)
     return KX_EINVAL;
+  int device = 0;
+  KX_HIP_TRY(hipGetDevice(&device));
   auto* g = new PeerGroup();
   g->world = world_size;
   g->rank = rank;
-  KX_HIP_TRY(hipGetDevice(&g->device));
+  g->device = device;
   g->cap = (max_floats + 63) / 64 * 64;
   g->flags_off = 2 * (size_t)world_size * g->cap * sizeof(float);
   g->box_bytes = g->flags_off + 2 * (size_t)world_size * kx::kPeerFlagStride;

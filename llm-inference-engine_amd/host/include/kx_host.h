@@ -42,6 +42,7 @@ int kxm_init_comm(void* model, const void* id128);
 int kxm_peer_create(void* model, uint64_t max_floats, void* handle64);
 int kxm_peer_connect(void* model, const void* handles);
 int kxm_peer_timed_out(void* model, int32_t* flag);
+int kxm_peer_disable(void* model);
 /* Row sub-blocks of the row-parallel prompt GEMMs under tensor parallelism: the all-reduce of one
  * sub-block runs on the side stream beside the GEMM of the next (1 = no overlap; default 4). */
 int kxm_set_prefill_subblocks(void* model, int32_t n);

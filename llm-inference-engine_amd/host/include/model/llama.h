@@ -113,6 +113,7 @@ class LlamaModel {
   base::Status peer_create(size_t max_floats, void* handle64);
   base::Status peer_connect(const void* handles);
   base::Status peer_timed_out(bool* flag) const;
+  void peer_disable();  // back to the RCCL path (the mailboxes stay mapped)
   // Test rig: the ranks of a tensor-parallel model as objects of one process (one thread each),
   // summing through a host rendezvous instead of RCCL.  Eager launches only.
   void join_loopback(std::shared_ptr<base::LoopbackGroup> group) { loop_ = std::move(group); }
@@ -198,7 +199,8 @@ class LlamaModel {
   bool comm_ready_ = false;
   void* peer_ = nullptr;        // peer-mailbox group; used once connected
   size_t peer_cap_ = 0;         // floats a peer collective carries at most
-  bool peer_connected_ = false;
+  bool peer_connected_ = false;  // collectives within the mailbox size take the peer path
+  bool peer_mapped_ = false;
   std::shared_ptr<base::LoopbackGroup> loop_;
   std::shared_ptr<kernel::CudaConfig> hip_;
   std::vector<LayerWeights> layers_;

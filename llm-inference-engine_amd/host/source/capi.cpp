@@ -90,6 +90,11 @@ int kxm_peer_create(void* m, uint64_t max_floats, void* handle64) {
   return done(M(m)->peer_create((size_t)max_floats, handle64));
 }
 int kxm_peer_connect(void* m, const void* handles) { return done(M(m)->peer_connect(handles)); }
+int kxm_peer_disable(void* m) {
+  if (!m) return -1;
+  M(m)->peer_disable();
+  return 0;
+}
 int kxm_peer_timed_out(void* m, int32_t* flag) {
   bool f = false;
   const int rc = done(M(m)->peer_timed_out(&f));

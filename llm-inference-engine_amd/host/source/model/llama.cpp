@@ -563,15 +563,25 @@ base::Status LlamaModel::peer_create(size_t max_floats, void* handle64) {
 }
 
 base::Status LlamaModel::peer_connect(const void* handles) {
-  if (!peer_ || peer_connected_) return base::error::InvalidArgument("peer_create() first, connect once");
+  if (!peer_ || peer_connected_ || peer_mapped_)
+    return base::error::InvalidArgument("peer_create() first, connect once");
   KX_RET(kx_peer_connect(peer_, handles));
-  peer_connected_ = true;
+  peer_connected_ = peer_mapped_ = true;
   // a step captured earlier holds the other collective
   if (graph_) {
     kx_graph_destroy(graph_);
     graph_ = nullptr;
   }
   return base::error::Success();
+}
+
+void LlamaModel::peer_disable() {
+  if (!peer_connected_) return;
+  peer_connected_ = false;
+  if (graph_) {
+    kx_graph_destroy(graph_);
+    graph_ = nullptr;
+  }
 }
 
 base::Status LlamaModel::peer_timed_out(bool* flag) const {

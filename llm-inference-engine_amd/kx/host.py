@@ -60,6 +60,7 @@ def hlib():
         L.kxm_peer_create.argtypes = [_vp, C.c_uint64, _vp]
         L.kxm_peer_connect.argtypes = [_vp, _vp]
         L.kxm_peer_timed_out.argtypes = [_vp, C.POINTER(_i32)]
+        L.kxm_peer_disable.argtypes = [_vp]
         L.kxm_forward_layers.argtypes = [_vp, _i32, _i32, _vp]
         L.kxm_set_state.argtypes = [_vp, _i32, _i32]
         L.kxm_step_logits.argtypes = [_vp, _i32, _i32, _vp]
@@ -173,6 +174,9 @@ class Model:
         """handles: every rank's handle, ordered by rank.  Follow with a barrier between the ranks."""
         blob = C.create_string_buffer(b"".join(handles), 64 * len(handles))
         hcheck(hlib().kxm_peer_connect(self.h, blob), "kxm_peer_connect")
+
+    def peer_disable(self):
+        hcheck(hlib().kxm_peer_disable(self.h), "kxm_peer_disable")
 
     def peer_timed_out(self) -> bool:
         f = _i32(0)

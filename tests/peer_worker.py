@@ -46,6 +46,43 @@ def model_rank(rank, world, dist, out_path):
     sys.exit(0 if not timed_out else 1)
 
 
+def absent_rank(rank, world, dist, count):
+    """Rank 0 reduces, the other ranks never do: rank 0's wait must give up (4 s), raise the flag and
+    let the launch finish; a second call must then return without waiting again."""
+    import time
+    import kx
+    L = kx.lib()
+    kx.check(L.kx_set_device(0), "set_device")
+    st = kx.Stream()
+    g = C.c_void_p()
+    kx.check(L.kx_peer_create(C.byref(g), world, rank, count), "peer_create")
+    h = C.create_string_buffer(64)
+    kx.check(L.kx_peer_handle(g, h), "peer_handle")
+    handles = [None] * world
+    dist.all_gather_object(handles, h.raw)
+    kx.check(L.kx_peer_connect(g, C.create_string_buffer(b"".join(handles), 64 * world)), "peer_connect")
+    dist.barrier()
+    ok, first_s, second_s, flag = True, 0.0, 0.0, C.c_int32(0)
+    if rank == 0:
+        buf = kx.Buf.from_numpy(np.ones(count, np.float32))
+        t0 = time.perf_counter()
+        kx.check(L.kx_peer_allreduce_sum_f32(g, buf.ptr, count, st.ptr), "peer_allreduce")
+        st.sync()
+        first_s = time.perf_counter() - t0
+        kx.check(L.kx_peer_timed_out(g, C.byref(flag)), "peer_timed_out")
+        t0 = time.perf_counter()
+        kx.check(L.kx_peer_allreduce_sum_f32(g, buf.ptr, count, st.ptr), "peer_allreduce")
+        st.sync()
+        second_s = time.perf_counter() - t0
+        ok = flag.value == 1 and 2.0 < first_s < 20.0 and second_s < 1.0
+    dist.barrier()
+    kx.check(L.kx_peer_destroy(g), "peer_destroy")
+    print(json.dumps({"rank": rank, "ok": bool(ok), "timed_out": 0, "flag": flag.value, "first_s": first_s,
+                      "second_s": second_s}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
 def main():
     rank, world, port, count = (int(v) for v in sys.argv[1:5])
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -54,6 +91,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if len(sys.argv) > 5 and sys.argv[5] == "model":
         return model_rank(rank, world, dist, sys.argv[6])
+    if len(sys.argv) > 5 and sys.argv[5] == "absent":
+        return absent_rank(rank, world, dist, count)
     import kx
     L = kx.lib()
     kx.check(L.kx_set_device(0), "set_device")

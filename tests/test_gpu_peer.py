@@ -49,6 +49,13 @@ def test_peer_collectives_across_processes(world, count):
 
 
 @pytest.mark.gpu
+def test_peer_wait_gives_up_when_a_rank_is_absent():
+    # the bounded wait: a reduce whose partner never shows up ends after 4 s with the flag raised,
+    # and later calls on that group do not wait again
+    _run_ranks(2, 1024, ("absent",))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_tensor_parallel_model_across_processes(world, tmp_path):
     # The tensor-parallel model with one PROCESS per rank (all on this box's one GPU), every
