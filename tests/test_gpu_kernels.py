@@ -945,7 +945,13 @@ def test_flash_attention_golden(golden):
 @pytest.mark.parametrize("H,KVH,hs,S,pos,Tq,causal", [
     (8, 2, 64, 300, 255, 256, True), (8, 2, 128, 300, 299, 130, True), (4, 4, 64, 200, 150, 33, True),
     (14, 2, 128, 160, 159, 160, True), (16, 2, 128, 128, 100, 64, True), (6, 2, 64, 100, 99, 50, False),
-    (4, 2, 32, 70, 69, 70, True)])
+    (4, 2, 32, 70, 69, 70, True),
+    # caches of more than three tiles take the LDS-DMA form when fp16 copies exist: workgroups of 7,
+    # 6 and 5-as-4 waves (only waves 0..3 issue the pieces), 8 waves from 2 heads x 4 sub-blocks,
+    # 32-wide heads, one head per kv head, a non-causal pass, rows that end inside a tile
+    (14, 2, 128, 280, 279, 200, True), (3, 1, 128, 330, 329, 150, True), (5, 1, 64, 260, 259, 100, True),
+    (4, 2, 128, 300, 299, 300, True), (4, 2, 32, 400, 399, 333, True), (2, 2, 64, 270, 269, 77, True),
+    (8, 1, 128, 256, 230, 40, False)])
 def test_flash_attention_vs_oracle(H, KVH, hs, S, pos, Tq, causal):
     rng = np.random.default_rng(H * 31 + Tq)
     L, layer = 2, 1
