@@ -1,4 +1,4 @@
-"""One rank of the peer-mailbox collectives test (tests/test_gpu_peer.py starts world_size of
+"""One rank of the peer-mailbox collectives test (tests/test_zy_gpu_peer.py starts world_size of
 these as separate processes, all on GPU 0, so the mailboxes really are mapped across processes
 through IPC handles).  Ranks meet over gloo on 127.0.0.1 to exchange the 64-byte handles.
 Prints one JSON line; exit status 0 only when every check of this rank passed."""
@@ -11,6 +11,46 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
+
+
+def all_ok(dist, ok):
+    """True when every rank's set-up step succeeded (a rank that cannot map the others' mailboxes
+    must not leave them waiting for it)."""
+    import torch
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0)
+
+
+def leave_skipped(dist, rank, why):
+    print(json.dumps({"rank": rank, "skip": why}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0)
+
+
+def connect_group(dist, L, kx, world, rank, count):
+    """Creates, exchanges and maps the mailboxes; returns (group, error text or None) with the same
+    verdict on every rank."""
+    g = C.c_void_p()
+    err = None
+    try:
+        kx.check(L.kx_peer_create(C.byref(g), world, rank, count), "peer_create")
+        h = C.create_string_buffer(64)
+        kx.check(L.kx_peer_handle(g, h), "peer_handle")
+        raw = h.raw
+    except kx.KxError as e:
+        err, raw = str(e), b"\0" * 64
+    handles = [None] * world
+    dist.all_gather_object(handles, raw)
+    if err is None:
+        try:
+            kx.check(L.kx_peer_connect(g, C.create_string_buffer(b"".join(handles), 64 * world)), "peer_connect")
+        except kx.KxError as e:
+            err = str(e)
+    if not all_ok(dist, err is None):
+        return g, err or "another rank could not set its mailbox up"
+    dist.barrier()  # every mailbox is zeroed and mapped before anybody writes
+    return g, None
 
 
 TP_SMALL = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
@@ -29,9 +69,21 @@ def model_rank(rank, world, dist, out_path):
     prompt = rng.integers(0, 700, 530).astype(np.int32)
     m = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, **TP_SMALL)
     m.init_synthetic(21)
+    err = None
+    try:
+        raw = m.peer_create(len(prompt) * TP_SMALL["dim"])
+    except kx.KxError as e:
+        err, raw = str(e), b"\0" * 64
     handles = [None] * world
-    dist.all_gather_object(handles, m.peer_create(len(prompt) * TP_SMALL["dim"]))
-    m.peer_connect(handles)
+    dist.all_gather_object(handles, raw)
+    if err is None:
+        try:
+            m.peer_connect(handles)
+        except kx.KxError as e:
+            err = str(e)
+    if not all_ok(dist, err is None):
+        m.close()
+        leave_skipped(dist, rank, err or "another rank could not set its mailbox up")
     dist.barrier()
     steps = np.stack([m.step_logits(int(t), p) for p, t in enumerate(toks)])
     last = m.prefill(prompt)
@@ -54,14 +106,9 @@ def absent_rank(rank, world, dist, count):
     L = kx.lib()
     kx.check(L.kx_set_device(0), "set_device")
     st = kx.Stream()
-    g = C.c_void_p()
-    kx.check(L.kx_peer_create(C.byref(g), world, rank, count), "peer_create")
-    h = C.create_string_buffer(64)
-    kx.check(L.kx_peer_handle(g, h), "peer_handle")
-    handles = [None] * world
-    dist.all_gather_object(handles, h.raw)
-    kx.check(L.kx_peer_connect(g, C.create_string_buffer(b"".join(handles), 64 * world)), "peer_connect")
-    dist.barrier()
+    g, err = connect_group(dist, L, kx, world, rank, count)
+    if err:
+        leave_skipped(dist, rank, err)
     ok, first_s, second_s, flag = True, 0.0, 0.0, C.c_int32(0)
     if rank == 0:
         buf = kx.Buf.from_numpy(np.ones(count, np.float32))
@@ -97,14 +144,9 @@ def main():
     L = kx.lib()
     kx.check(L.kx_set_device(0), "set_device")
     st = kx.Stream()
-    g = C.c_void_p()
-    kx.check(L.kx_peer_create(C.byref(g), world, rank, count), "peer_create")
-    h = C.create_string_buffer(64)
-    kx.check(L.kx_peer_handle(g, h), "peer_handle")
-    handles = [None] * world
-    dist.all_gather_object(handles, h.raw)
-    kx.check(L.kx_peer_connect(g, C.create_string_buffer(b"".join(handles), 64 * world)), "peer_connect")
-    dist.barrier()  # every mailbox is zeroed and mapped before anybody writes
+    g, err = connect_group(dist, L, kx, world, rank, count)
+    if err:
+        leave_skipped(dist, rank, err)
 
     def vec(r, it, n):
         return np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float32)

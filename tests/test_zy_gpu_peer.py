@@ -1,4 +1,5 @@
-"""Peer-mailbox collectives across PROCESSES: world_size ranks, each its own process, all on the
+"""(Named to be collected near the end: these tests start several GPU processes.)
+Peer-mailbox collectives across PROCESSES: world_size ranks, each its own process, all on the
 one GPU of the box; mailboxes mapped through IPC handles.  Sums must equal the fp32 sum taken in
 rank order bit for bit, on every rank, eagerly and under graph replay."""
 import json
@@ -36,9 +37,16 @@ def _run_ranks(world, count, extra=()):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    recs = []
     for rc, out, err in outs:
         assert rc == 0, f"rank failed (rc {rc}):\n{out}\n{err[-2000:]}"
-        rec = json.loads(out.strip().splitlines()[-1])
+        recs.append(json.loads(out.strip().splitlines()[-1]))
+    # a box whose runtime cannot share device memory between processes (no IPC handles, no
+    # fine-grained allocations): every rank reports the set-up error and leaves; nothing was computed
+    skipped = [r["skip"] for r in recs if "skip" in r]
+    if skipped:
+        pytest.skip("peer mailboxes could not be set up on this box: " + skipped[0])
+    for rec in recs:
         assert rec["ok"] and rec["timed_out"] == 0, rec
 
 
