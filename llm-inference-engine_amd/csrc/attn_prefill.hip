@@ -297,13 +297,27 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
 
   // ---- fragment addresses (bytes inside a buffer) ----
   // DMA: K row qcol (+32 kt), chunk 2ks+half swizzled; V^T row qcol (+32 dt), chunk 4kt+2st+half
-  int koff[DMA ? KS : 1], voff[DMA ? 4 : 1];
+  // (LDS pointers of buffer 0, worked out once: inside the loop a fragment address is one of these
+  // plus a compile-time offset for buffer, key half and output tile, i.e. an instruction immediate)
+  // Each is pinned in a register of its own (the empty asm): left to itself hipcc splits them into
+  // a common part and a per-step part and adds the two again for every read of every tile.
+  using lds_cptr_t = const __attribute__((address_space(3))) char*;
+  using lds_frag_t = const __attribute__((address_space(3))) f16x8*;
+  lds_cptr_t kfrag[DMA ? KS : 1];
+  lds_cptr_t vfrag[DMA ? 4 : 1];
   if constexpr (DMA) {
     const int kkey = (qcol * DKCH / 16) % DKCH, vkey = (qcol >> 1) & 7;
+    lds_cptr_t base = (lds_cptr_t)smem;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) koff[ks] = qcol * DK_ROWB + (((2 * ks + half) ^ kkey) << 4);
+    for (int ks = 0; ks < KS; ++ks) {
+      kfrag[ks] = base + qcol * DK_ROWB + (((2 * ks + half) ^ kkey) << 4);
+      asm volatile("" : "+v"(kfrag[ks]));
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) voff[j] = DK_TILE_B + qcol * 128 + (((2 * j + half) ^ vkey) << 4);
+    for (int j = 0; j < 4; ++j) {
+      vfrag[j] = base + DK_TILE_B + qcol * 128 + (((2 * j + half) ^ vkey) << 4);
+      asm volatile("" : "+v"(vfrag[j]));
+    }
   }
 
   // ---- register staging roles (!DMA) ----
@@ -405,45 +419,54 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     if (key0 <= wave_last_pos) {
       const _Float16* Kl = lds + buf * BUF;
       const _Float16* Vl = Kl + K_TILE;
-      const char* Dl = smem + buf * DBUF_B;
       // ---- S^T[key][q] for the tile's two 32-key halves ----
       f32x16 s[2];
       f16x8 vf[2][DT];  // V^T fragments of two 16-key steps (DMA form)
       if constexpr (DMA) {
         // fragments are requested a stage ahead of the MFMAs that use them (read, then multiplied
-        // at once, every pair of MFMAs waited a full LDS round trip): the first key half's all
-        // at once, the second half's and the first V^T step's under the first half's MFMAs
-        constexpr int KH = KS / 2;
+        // at once, every pair of MFMAs waited a full LDS round trip), half a 32-key block of K at
+        // a time, so the first MFMAs of a tile wait for four reads, not eight; the first V^T
+        // step's fragments travel under the last stage's MFMAs
+        constexpr int KH = KS / 2 > 0 ? KS / 2 : 1;
         f16x8 ka[KS], kb[KS];
+        auto kread = [&](f16x8 (&dst)[KS], int kt, int k0, int k1) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          ka[ks] = *reinterpret_cast<const f16x8*>(Dl + koff[ks]);
+          for (int ks = k0; ks < k1; ++ks)
+            dst[ks] = *(lds_frag_t)(kfrag[ks] + buf * DBUF_B + kt * 32 * DK_ROWB);
+        };
+        auto kmul = [&](f32x16& acc, const f16x8 (&src)[KS], int k0, int k1) {
+#pragma unroll
+          for (int ks = k0; ks < k1; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[ks], qf[ks], acc, 0, 0, 0);
+        };
+        kread(ka, 0, 0, KH);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KH; ++ks)
-          kb[ks] = *reinterpret_cast<const f16x8*>(Dl + 32 * DK_ROWB + koff[ks]);
-#pragma unroll
-        for (int ks = 0; ks < KH; ++ks)
-          s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[ks], s[0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = KH; ks < KS; ++ks)
-          kb[ks] = *reinterpret_cast<const f16x8*>(Dl + 32 * DK_ROWB + koff[ks]);
-#pragma unroll
-        for (int ks = KH; ks < KS; ++ks)
-          s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[ks], s[0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+// hipcc waits for ALL outstanding LDS reads in front of the first MFMA that needs one (always
+// lgkmcnt(0) in a kernel with LDS-DMA), so a stage opens with one MFMA -- whose operands were
+// requested a stage ago -- then requests the next stage's fragments, then issues its other MFMAs
+#define FA_STAGE_ORDER(reads, mfmas)                                       \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           /* MFMA */  \
+  __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);       /* reads */ \
+  __builtin_amdgcn_sched_group_barrier(0x008, (mfmas) - 1, 0);             \
+  __builtin_amdgcn_sched_barrier(0)
+        kread(ka, 0, KH, KS);
+        kmul(s[0], ka, 0, KH);
+        FA_STAGE_ORDER(KS - KH, KH);
+        kread(kb, 1, 0, KH);
+        kmul(s[0], ka, KH, KS);
+        FA_STAGE_ORDER(KH, KS - KH);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[1][r] = 0.f;
+        kread(kb, 1, KH, KS);
+        kmul(s[1], kb, 0, KH);
+        FA_STAGE_ORDER(KS - KH, KH);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-          vf[0][dt] = *reinterpret_cast<const f16x8*>(Dl + dt * 32 * 128 + voff[0]);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb[ks], qf[ks], s[1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          vf[0][dt] = *(lds_frag_t)(vfrag[0] + buf * DBUF_B + dt * 32 * 128);
+        kmul(s[1], kb, KH, KS);
+        FA_STAGE_ORDER(DT, KS - KH);
       } else {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -521,7 +544,7 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
               vf[(g + 1) & 1][dt] =
-                  *reinterpret_cast<const f16x8*>(Dl + dt * 32 * 128 + voff[g + 1]);
+                  *(lds_frag_t)(vfrag[g + 1] + buf * DBUF_B + dt * 32 * 128);
           }
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt)
