@@ -55,9 +55,13 @@ def connect_group(dist, L, kx, world, rank, count):
 
 TP_SMALL = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+# Qwen2 traits: q/k/v biases, theta 1e6, eps 1e-6, four query heads per kv head
+TP_QWEN = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=700,
+               rope_variant=1, rope_theta=1e6, rms_eps=1e-6)
+MODEL_SHAPES = {"llama": (TP_SMALL, False), "qwen": (TP_QWEN, True)}
 
 
-def model_rank(rank, world, dist, out_path):
+def model_rank(rank, world, dist, out_path, family="llama"):
     """One tensor-parallel rank of a small model whose collectives all go through the peer
     mailboxes: ten single steps, a 530-row batched prompt, six greedy steps under graph replay."""
     import kx
@@ -67,11 +71,12 @@ def model_rank(rank, world, dist, out_path):
     rng = np.random.default_rng(5)
     toks = rng.integers(0, 700, 10).astype(np.int32)
     prompt = rng.integers(0, 700, 530).astype(np.int32)
-    m = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, **TP_SMALL)
+    shape, bias = MODEL_SHAPES[family]
+    m = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, qkv_bias=bias, **shape)
     m.init_synthetic(21)
     err = None
     try:
-        raw = m.peer_create(len(prompt) * TP_SMALL["dim"])
+        raw = m.peer_create(len(prompt) * shape["dim"])
     except kx.KxError as e:
         err, raw = str(e), b"\0" * 64
     handles = [None] * world
@@ -137,7 +142,7 @@ def main():
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if len(sys.argv) > 5 and sys.argv[5] == "model":
-        return model_rank(rank, world, dist, sys.argv[6])
+        return model_rank(rank, world, dist, sys.argv[6], sys.argv[7] if len(sys.argv) > 7 else "llama")
     if len(sys.argv) > 5 and sys.argv[5] == "absent":
         return absent_rank(rank, world, dist, count)
     import kx

@@ -64,26 +64,26 @@ def test_peer_wait_gives_up_when_a_rank_is_absent():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_tensor_parallel_model_across_processes(world, tmp_path):
+@pytest.mark.parametrize("world,family", [(2, "llama"), (4, "llama"), (2, "qwen")])
+def test_tensor_parallel_model_across_processes(world, family, tmp_path):
     # The tensor-parallel model with one PROCESS per rank (all on this box's one GPU), every
     # collective of the token loop and of the prompt pass through the peer mailboxes, the greedy
     # steps under graph replay: all ranks agree bit for bit, and match the unsharded model run here
     # to the bound of the in-process rig (row-parallel sums are re-associated).
     import peer_worker
     from kx import host
-    shape = peer_worker.TP_SMALL
+    shape, bias = peer_worker.MODEL_SHAPES[family]
     rng = np.random.default_rng(5)
     toks = rng.integers(0, 700, 10).astype(np.int32)
     prompt = rng.integers(0, 700, 530).astype(np.int32)
-    one = host.Model(seq_len=576, group_size=64, **shape)
+    one = host.Model(seq_len=576, group_size=64, qkv_bias=bias, **shape)
     one.init_synthetic(21)
     want = np.stack([one.step_logits(int(t), p) for p, t in enumerate(toks)])
     ref_last = one.prefill(prompt)
     one.decode(6, use_graph=True)
     ref_hist = one.history(len(prompt) + 7)
     one.close()
-    _run_ranks(world, 4096, ("model", str(tmp_path / "rank%r.npz")))
+    _run_ranks(world, 4096, ("model", str(tmp_path / "rank%r.npz"), family))
     got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for r in range(world):
         assert int(got[r]["timed_out"][0]) == 0
