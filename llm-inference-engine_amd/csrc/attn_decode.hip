@@ -234,8 +234,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       float sv[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {  // sum of the four dim quarters
-        sv[r] += lane_xor16(sv[r]);
-        sv[r] += lane_xor32(sv[r]);
+        sv[r] = xor16_sum(sv[r]);
+        sv[r] = xor32_sum(sv[r]);
         sv[r] *= scale;
         if (key0 + 4 * kb + r > last) sv[r] = -INFINITY;
       }
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     float oo[4][4];  // [head r][t], both key parities
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      oo[0][e] = o[e].x + lane_xor32(o[e].x);
-      oo[1][e] = o[e].y + lane_xor32(o[e].y);
-      oo[2][e] = o[e].z + lane_xor32(o[e].z);
-      oo[3][e] = o[e].w + lane_xor32(o[e].w);
+      oo[0][e] = xor32_sum(o[e].x);
+      oo[1][e] = xor32_sum(o[e].y);
+      oo[2][e] = xor32_sum(o[e].z);
+      oo[3][e] = xor32_sum(o[e].w);
     }
     if (lane < 32) {
 #pragma unroll
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     for (int r = 0; r < 4; ++r)
       if (key0 + 4 * g + r > last) sv[r] = -INFINITY;
     float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-    mx = fmaxf(mx, lane_xor16(mx));
-    mx = fmaxf(mx, lane_xor32(mx));
+    mx = xor16_max(mx);
+    mx = xor32_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = fast_exp(m_run - m_new);  // first tile: exp(-inf) = 0
     m_run = m_new;
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   }
 
   // ---- wave result -> LDS.  lane (head n, g'): o[h][e][r'] = O[head][64h + 4(4g'+r') + e] ----
-  l_run += lane_xor16(l_run);
-  l_run += lane_xor32(l_run);
+  l_run = xor16_sum(l_run);
+  l_run = xor32_sum(l_run);
   if (n < kv_mul) {
     if (g == 0) {
       sm_m[wave][n] = m_run;

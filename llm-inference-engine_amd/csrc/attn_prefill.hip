@@ -113,14 +113,6 @@ __device__ unsigned long long fa_trace_buf[8][16];
 #define FA_STAMP(i)
 #endif
 
-// max of a value with its partner 32 lanes away, in every lane: one v_permlane32_swap hands each
-// half of the wave the other half's values (no trip through LDS as ds_bpermute takes)
-__device__ __forceinline__ float fa_halves_max(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-
 // A wave's 32 x HS output tile leaves through LDS: the accumulators hold "lane = query row", so
 // direct stores put 16 bytes per lane at a row stride (64 row segments per instruction, every
 // 128-byte line written by four instructions); turned around in the wave's own LDS region, an
@@ -503,7 +495,7 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-      mx = fa_halves_max(mx);
+      mx = xor32_max(mx);
       // Lazy running max: the reference point of the exponentials only moves when some row's
       // new maximum exceeds the old one by more than 2^kLazy (scores are in the log2 domain).
       // Softmax does not depend on the reference point; keeping it makes alpha = 1 and skips the
@@ -634,7 +626,7 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
 #endif
 
   // ---- epilogue: lane (q row, half) holds O[row][32dt + 8g + 4half + e] in o[dt][4g+e] ----
-  l_run += lane_xor32(l_run);
+  l_run = xor32_sum(l_run);
   const float inv = 1.0f / l_run;
   bool stored = false;
   if constexpr (DMA) {

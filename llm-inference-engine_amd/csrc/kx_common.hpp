@@ -81,17 +81,54 @@ __device__ __forceinline__ float lane_xor32(float v) {
       float, __builtin_amdgcn_ds_bpermute(((lane ^ 32) << 2), __builtin_bit_cast(int, v)));
 }
 
+// v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows (upper 32 lanes) of the first
+// register with the even rows (lower 32 lanes) of the second.  Called with two copies of one value,
+// the first register ends up holding the even rows' (lower half's) values in both positions and the
+// second the odd rows' (upper half's): "mine" and "my partner's" in every lane, on the vector ALU,
+// where ds_swizzle / ds_bpermute above take a trip through the LDS pipeline and an lgkmcnt wait.
+// Written as inline assembly because this toolchain's __builtin_amdgcn_permlane{16,32}_swap returns
+// its first result in both elements of the pair.  The s_nop covers the wait states the swap needs
+// after a vector-ALU write of either register.
+__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// Sum / maximum of a value with its partner 16 or 32 lanes away, in every lane.  Addition and
+// maximum are commutative, so the results equal those of v + lane_xor16(v) etc. bit for bit.
+__device__ __forceinline__ float xor16_sum(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane32_swap(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane32_swap(a, b);
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
 // Full 64-lane sum; every lane receives it.
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
-  v += lane_xor16(v);
-  v += lane_xor32(v);
+  v = xor16_sum(v);
+  v = xor32_sum(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = row16_max(v);
-  v = fmaxf(v, lane_xor16(v));
-  v = fmaxf(v, lane_xor32(v));
+  v = xor16_max(v);
+  v = xor32_max(v);
   return v;
 }
 

@@ -1001,6 +1001,32 @@ def test_flash_attention_forced_rescale_and_last_row_equals_decode():
     np.testing.assert_allclose(got[-1], last, rtol=0, atol=3e-3)
 
 
+@pytest.mark.parametrize("hs", [128, 64])
+def test_flash_attention_one_dominant_key_per_tile(hs):
+    # Every 64-key tile holds one key whose score beats everything before it by ~17 (natural log
+    # units), at a different position inside each tile.  The tile's running maximum has to be the
+    # maximum over ALL of the tile's keys, whichever lanes hold them: taken over a part of them, the
+    # probabilities of the rest leave fp16's range on their way into the PV product.
+    rng = np.random.default_rng(hs)
+    H, KVH, S = 4, 2, 512
+    pos, Tq = S - 1, S
+    u = rng.standard_normal(hs).astype(np.float32)
+    u *= np.sqrt(hs) / np.linalg.norm(u)
+    q = (u + 0.05 * rng.standard_normal((Tq, H, hs))).astype(np.float32)
+    kc = (0.02 * rng.standard_normal((1, S, KVH * hs))).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    for t in range(S // 64):
+        key = 64 * t + (5 * t + 2) % 64
+        kc[0, key] = np.tile(u, KVH) * (1.5 * (t + 1) * np.sqrt(128.0 / hs))
+    want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, 0, threads=8)
+    for f16_copies in (True, False):
+        got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0, f16_copies=f16_copies)
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
+    last = kx.mha_decode(q[-1].reshape(-1), kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(last, want[-1], rtol=0, atol=3e-3)
+
+
 # ---------------- 16-bit KV cache ---------------------------------------------------------------------
 @pytest.mark.parametrize("H,KVH,hs,S,pos", [(32, 8, 128, 600, 599), (8, 2, 64, 100, 37), (4, 4, 32, 40, 0),
                                             (28, 4, 128, 1100, 1099)])
