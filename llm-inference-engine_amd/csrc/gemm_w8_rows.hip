@@ -1,5 +1,5 @@
-// W8A16 group-quant product for a FEW activation rows (2..64) on gfx950:
-//   Y[t][p] = sum_i X[t][i] * scales[(p*M+i)/64] * (float)w[p*M+i],   t < T <= 64.
+// W8A16 group-quant product for a FEW activation rows (2..128) on gfx950:
+//   Y[t][p] = sum_i X[t][i] * scales[(p*M+i)/64] * (float)w[p*M+i],   t < T <= 128.
 //
 // The reference has no batched matmul (its prompt phase feeds one token per launch,
 // demo/main.cpp:18-41; cuda/matmul_kernel.cu:89-134 ignore a second input dim).  With so few rows
@@ -51,7 +51,7 @@ constexpr int FR_SLOT = 4096;  // one unit of a wave's 32 rows
 constexpr int FR_SRING = 3;    // scale slots per compute wave: 1 KiB = the scales of four units
 constexpr int FR_WAVE_LDS = FR_RING * FR_SLOT + FR_SRING * 1024;
 constexpr size_t kRowsTicketBytes = 4096;
-constexpr size_t kRowsX16Bytes = 4u << 20;  // fp16 copy of fp32 activation rows (64 x 32768 at most)
+constexpr size_t kRowsX16Bytes = 4u << 20;  // fp16 copy of fp32 activation rows (64 x 32768, 128 x 16384)
 
 struct RowsArgs {
   const _Float16* X;    // [T][ldx] fp16
@@ -121,6 +121,10 @@ __device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TB], __amdgpu_buffe
 // activation unit buffers: as many as LDS has room for beside the weight rings
 template <int TB>
 constexpr int rows_xbufs() { return TB == 1 ? 4 : TB == 2 ? 2 : 3; }
+// the activation wave counts its requests with vmcnt (6 bits): the units in flight behind the one
+// it waits for must stay below 64 instructions
+template <int TB>
+constexpr bool rows_counts_fit() { return (rows_xbufs<TB>() - 2) * TB * 4 < 64; }
 // LDS: [activation unit buffers: TB x 4 KiB each][per compute wave: weight ring, scale ring]
 template <int TB>
 constexpr int rows_lds_bytes() { return rows_xbufs<TB>() * TB * 4096 + 4 * FR_WAVE_LDS; }
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
     un = base + (part < rem ? 1 : 0);
   }
   constexpr int NXB = rows_xbufs<TB>();
+  static_assert(rows_counts_fit<TB>() && rows_lds_bytes<TB>() <= 160 * 1024, "token blocks per unit");
   char* const xbuf = smem;
   char* const ring = smem + NXB * XBUF + (wave & 3) * FR_WAVE_LDS;
   char* const sring = ring + FR_RING * FR_SLOT;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
       const int younger = min(NXB - 2, un - 1 - u);
       if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TB * 4) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TB * 8) : "memory");
+      else if constexpr (NXB > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TB * 8) : "memory");
       __builtin_amdgcn_s_barrier();  // unit u is in place; unit u - 1 has been multiplied by every wave
       if (u + NXB - 1 < un) issue_x(u + NXB - 1);
     }
@@ -405,7 +410,7 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
   const int xalign = x_half ? 8 : 4;
   // M % 256: a row's scales then start on a 16-byte boundary
-  if (T > 64 || group_size != 64 || M % 256 != 0 || ldx % xalign != 0 || ((uintptr_t)X % 16) != 0 ||
+  if (T > 128 || group_size != 64 || M % 256 != 0 || ldx % xalign != 0 || ((uintptr_t)X % 16) != 0 ||
       ((uintptr_t)w % 16) != 0 || ((uintptr_t)scales % 16) != 0)
     return KX_EUNSUPPORTED;
   const int tiles = (K + FR_BN - 1) / FR_BN, nu = M / FR_KU;
@@ -426,7 +431,7 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
     X = x16;
     ldx = M;
   }
-  const int TB = T <= 16 ? 1 : T <= 32 ? 2 : 4;
+  const int TB = T <= 16 ? 1 : T <= 32 ? 2 : T <= 64 ? 4 : T <= 96 ? 6 : 8;
   const size_t slab_bytes = have_ws ? split_ws_bytes - kRowsTicketBytes - kRowsX16Bytes : 0;
   int S = rows_split_choice(tiles, nu, TB, slab_bytes);
   if (const char* e = getenv("KX_ROWS_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
@@ -446,7 +451,9 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   switch (TB) {
     case 1: return launch_rows<1>(a, s);
     case 2: return launch_rows<2>(a, s);
-    default: return launch_rows<4>(a, s);
+    case 4: return launch_rows<4>(a, s);
+    case 6: return launch_rows<6>(a, s);
+    default: return launch_rows<8>(a, s);
   }
 }
 
