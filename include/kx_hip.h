@@ -209,14 +209,14 @@ int kx_gemm_w8_f16act_split_ws(const void* X16, const int8_t* w, const float* sc
                                const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
                                void* workspace, size_t workspace_bytes, void* split_workspace,
                                size_t split_workspace_bytes, void* stream);
-/* The same product for FEW rows (2 <= T <= 128; a short prompt, the reference feeds such rows one
+/* The same product for FEW rows (2 <= T <= 192; a short prompt, the reference feeds such rows one
  * launch each, demo/main.cpp:18-41): the int8 weights are streamed once, as by the decode GEMV,
  * and meet all T activation rows on the matrix cores.  Arithmetic as kx_gemm_w8_f32 (activations
  * rounded to fp16, one fp32 partial per 64-group times its fp32 scale).  Routing, residual and
  * leading dimensions as kx_gemm_w8_f32_ex; X is fp32 rows (_f32) or fp16 rows (_f16act, ldx in
  * halves).  split_workspace as for kx_gemm_w8_f16act_split_ws (tickets zero before first use,
  * left zero; NULL: reductions are never cut over workgroups, slow on narrow matrices).
- * KX_EUNSUPPORTED for T > 128, group_size != 64, M % 256 != 0 or unaligned operands: run
+ * KX_EUNSUPPORTED for T > 192, group_size != 64, M % 256 != 0 or unaligned operands: run
  * kx_gemm_w8_f32_ex instead. */
 int kx_gemm_w8_rows_f32(const float* X, int64_t ldx, const int8_t* w, const float* scales,
                         int32_t group_size, float* y0, int64_t ld0, float* y1, int64_t ld1,

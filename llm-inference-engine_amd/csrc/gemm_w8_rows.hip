@@ -1,5 +1,5 @@
-// W8A16 group-quant product for a FEW activation rows (2..128) on gfx950:
-//   Y[t][p] = sum_i X[t][i] * scales[(p*M+i)/64] * (float)w[p*M+i],   t < T <= 128.
+// W8A16 group-quant product for a FEW activation rows (2..192) on gfx950:
+//   Y[t][p] = sum_i X[t][i] * scales[(p*M+i)/64] * (float)w[p*M+i],   t < T <= 192.
 //
 // The reference has no batched matmul (its prompt phase feeds one token per launch,
 // demo/main.cpp:18-41; cuda/matmul_kernel.cu:89-134 ignore a second input dim).  With so few rows
@@ -45,13 +45,15 @@ using lds_ptr_t = __attribute__((address_space(3))) void*;
 
 constexpr int FR_BN = 128;     // weight rows per workgroup
 constexpr int FR_KU = 128;     // reduction elements per unit
-constexpr int FR_RING = 3;     // weight unit slots per compute wave
-constexpr int FR_AHEAD = FR_RING - 1;
 constexpr int FR_SLOT = 4096;  // one unit of a wave's 32 rows
 constexpr int FR_SRING = 3;    // scale slots per compute wave: 1 KiB = the scales of four units
-constexpr int FR_WAVE_LDS = FR_RING * FR_SLOT + FR_SRING * 1024;
+// weight unit slots per compute wave
+template <int TB>
+constexpr int rows_ring() { return 3; }
+template <int TB>
+constexpr int rows_wave_lds() { return rows_ring<TB>() * FR_SLOT + FR_SRING * 1024; }
 constexpr size_t kRowsTicketBytes = 4096;
-constexpr size_t kRowsX16Bytes = 4u << 20;  // fp16 copy of fp32 activation rows (64 x 32768, 128 x 16384)
+constexpr size_t kRowsX16Bytes = 8u << 20;  // fp16 copy of fp32 activation rows (128 x 32768, 192 x 16384)
 
 struct RowsArgs {
   const _Float16* X;    // [T][ldx] fp16
@@ -94,19 +96,22 @@ __device__ __forceinline__ void wait_dma(int n) {
   }
 #undef KX_W
 }
-static_assert(4 * FR_AHEAD + 2 <= 22, "wait_dma covers the units in flight and their scale fetches");
+static_assert(4 * (3 - 1) + 2 <= 22, "wait_dma covers the units in flight and their scale fetches");
 
-template <int S, int TB>
-__device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TB], __amdgpu_buffer_rsrc_t rs, unsigned lane_off) {
+// TB: token blocks of the tile, TBW: this wave's share of them, starting at block tb0
+template <int S, int TB, int TBW>
+__device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TBW], __amdgpu_buffer_rsrc_t rs, unsigned lane_off,
+                                             int tb0) {
   constexpr unsigned PB = TB * 8192u;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) {
+    for (int tb = 0; tb < TBW; ++tb) {
       u32x4 v[S];
 #pragma unroll
       for (int p = 0; p < S; ++p)
-        v[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)p * PB + lane_off + (rb * TB + tb) * 1024, 0, 16);
+        v[p] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (unsigned)p * PB + lane_off + (unsigned)((rb * TB + tb0 + tb) * 1024), 0, 16);
       f32x4 t = {__uint_as_float(v[0].x), __uint_as_float(v[0].y), __uint_as_float(v[0].z),
                  __uint_as_float(v[0].w)};
 #pragma unroll
@@ -120,17 +125,24 @@ __device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TB], __amdgpu_buffe
 
 // activation unit buffers: as many as LDS has room for beside the weight rings
 template <int TB>
-constexpr int rows_xbufs() { return TB == 1 ? 4 : TB == 2 ? 2 : 3; }
+constexpr int rows_xbufs() { return TB == 1 ? 4 : TB == 2 || TB > 8 ? 2 : 3; }
 // the activation wave counts its requests with vmcnt (6 bits): the units in flight behind the one
 // it waits for must stay below 64 instructions
 template <int TB>
 constexpr bool rows_counts_fit() { return (rows_xbufs<TB>() - 2) * TB * 4 < 64; }
 // LDS: [activation unit buffers: TB x 4 KiB each][per compute wave: weight ring, scale ring]
 template <int TB>
-constexpr int rows_lds_bytes() { return rows_xbufs<TB>() * TB * 4096 + 4 * FR_WAVE_LDS; }
+constexpr int rows_lds_bytes() { return rows_xbufs<TB>() * TB * 4096 + 4 * rows_wave_lds<TB>(); }
 
-template <int TB>
-__global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) {
+// PAIR = 1: four compute waves, each with all TB token blocks of its 32 weight rows.
+// PAIR = 2: eight compute waves; waves w and w + 4 share wave w's weight ring (wave w requests it)
+// and take half of the token blocks each, so every SIMD holds two compute waves and one's LDS
+// reads, conversions and scale updates run beside the other's matrix instructions.
+template <int TB, int PAIR>
+__global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(const RowsArgs a) {
+  static_assert(PAIR == 1 || (PAIR == 2 && TB % 2 == 0), "token blocks split evenly over a pair");
+  constexpr int NCW = 4 * PAIR;    // compute waves; wave NCW brings in the activation rows
+  constexpr int TBW = TB / PAIR;   // token blocks per compute wave
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int XBUF = TB * 4096;  // one activation unit: 2 groups x TB token blocks x 2 halves x 1 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -146,18 +158,21 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
     un = base + (part < rem ? 1 : 0);
   }
   constexpr int NXB = rows_xbufs<TB>();
+  constexpr int FR_RING = rows_ring<TB>(), FR_AHEAD = FR_RING - 1, FR_WAVE_LDS = rows_wave_lds<TB>();
   static_assert(rows_counts_fit<TB>() && rows_lds_bytes<TB>() <= 160 * 1024, "token blocks per unit");
   char* const xbuf = smem;
   char* const ring = smem + NXB * XBUF + (wave & 3) * FR_WAVE_LDS;
   char* const sring = ring + FR_RING * FR_SLOT;
 
-  f32x4 acc[2][TB];
+  const int tb0 = (wave >> 2) * TBW;  // first token block of a compute wave
+  const bool requests = wave < 4;     // the wave that requests the ring's weights
+  f32x4 acc[2][TBW];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) acc[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tb = 0; tb < TBW; ++tb) acc[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (wave == 4) {
+  if (wave == NCW) {
     // ---- activation rows: one instruction = 8 tokens x 128 bytes (one quant group) ----
     // lane (r8, s) = (lane >> 3, lane & 7) fetches piece s ^ key of its token, key from the
     // token's index inside its block of 16 with bits 0 and 1 of (index >> 1) exchanged
@@ -209,17 +224,18 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
       for (int h = 0; h < 2; ++h) {
         const int r8 = lane >> 3, key = h * 4 + (r8 >> 1);
         // rows past the end re-read the last row; their results are never stored
-        const unsigned n = (unsigned)min(n0 + wave * 32 + rb * 16 + h * 8 + r8, a.K - 1);
+        const unsigned n = (unsigned)min(n0 + (wave & 3) * 32 + rb * 16 + h * 8 + r8, a.K - 1);
         woff[rb][h] = n * (unsigned)a.M + (unsigned)u0 * FR_KU + (unsigned)(((lane & 7) ^ key) * 16);
       }
     {
       // lanes 0-31: the rows' first 16 bytes of a four-unit block of scales, lanes 32-63: the second
-      const unsigned n = (unsigned)min(n0 + wave * 32 + (lane & 31), a.K - 1);
+      const unsigned n = (unsigned)min(n0 + (wave & 3) * 32 + (lane & 31), a.K - 1);
       soff = n * (unsigned)(a.M / 64) * 4u + (unsigned)(lane >> 5) * 16u;
     }
     const char* const wbase = reinterpret_cast<const char*>(a.w);
     const char* const sbase = reinterpret_cast<const char*>(a.scales);
     auto issue_w = [&](int u) {
+      if (!requests) return;
       char* dst = ring + (u % FR_RING) * FR_SLOT;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
@@ -252,14 +268,18 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
     for (int u = 0; u < FR_AHEAD; ++u)
       if (u < un) issue_w(u);
     for (int u = 0; u < un; ++u) {
-      if (u + FR_AHEAD < un) issue_w(u + FR_AHEAD);
-      {
+      // A ring of its own a wave refills before the barrier (the slot's last reads were its own).
+      // A shared ring is refilled behind the barrier: the slot of unit u + FR_AHEAD held unit u - 1,
+      // which the partner wave may still be reading until it arrives here.
+      if (PAIR == 1 && u + FR_AHEAD < un) issue_w(u + FR_AHEAD);
+      if (requests) {
         // younger than unit u's: four instructions per unit requested since, one more per block of
         // scales that started among them
-        const int k = min(FR_AHEAD, un - 1 - u);
+        const int k = min(PAIR == 1 ? FR_AHEAD : FR_AHEAD - 1, un - 1 - u);
         wait_dma(4 * k + (((u0 + u + k) >> 2) - ((u0 + u) >> 2)));
       }
       __builtin_amdgcn_s_barrier();
+      if (PAIR == 2 && u + FR_AHEAD < un) issue_w(u + FR_AHEAD);
       __builtin_amdgcn_sched_barrier(0);
       const char* slot = ring + (u % FR_RING) * FR_SLOT;
       const char* xb = xbuf + (u % NXB) * XBUF;
@@ -270,12 +290,12 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
       for (int rb = 0; rb < 2; ++rb) sv[rb] = *reinterpret_cast<const f32x4*>(sslot + (rb * 16 + j) * 16);
 #pragma unroll
       for (int gl = 0; gl < 2; ++gl) {
-        f16x8 xa[TB][2];
+        f16x8 xa[TBW][2];
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb)
+        for (int tb = 0; tb < TBW; ++tb)
 #pragma unroll
           for (int m = 0; m < 2; ++m)
-            xa[tb][m] = *reinterpret_cast<const f16x8*>(xb + (gl * TB + tb) * 2048 + rdx[m]);
+            xa[tb][m] = *reinterpret_cast<const f16x8*>(xb + (gl * TB + tb0 + tb) * 2048 + rdx[m]);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const u32x4 wv = *reinterpret_cast<const u32x4*>(slot + rb * 2048 + rdw[gl]);
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
           const f16x8 w1 = cvt_w8x8(wv.z, wv.w);
           const float sc = sel ? (gl ? sv[rb][3] : sv[rb][2]) : (gl ? sv[rb][1] : sv[rb][0]);
 #pragma unroll
-          for (int tb = 0; tb < TB; ++tb) {
+          for (int tb = 0; tb < TBW; ++tb) {
             f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tb][0], w0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tb][1], w1, g, 0, 0, 0);
             // Element by element on purpose (this file is built without SLP vectorisation): as
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
     }
   }
 
-  const bool computes = wave < 4;
+  const bool computes = wave < NCW;
   if (nsplit > 1) {
     constexpr unsigned PB = TB * 8192u;  // one part's partial tile: [wave][row block][token block][lane] x 16 B
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -311,11 +331,12 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
+        for (int tb = 0; tb < TBW; ++tb) {
           u32x4 v;
           v.x = __float_as_uint(acc[rb][tb][0]); v.y = __float_as_uint(acc[rb][tb][1]);
           v.z = __float_as_uint(acc[rb][tb][2]); v.w = __float_as_uint(acc[rb][tb][3]);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)part * PB + lane_off + (rb * TB + tb) * 1024, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(
+              v, rs, (unsigned)part * PB + lane_off + (unsigned)((rb * TB + tb0 + tb) * 1024), 0, 16);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -326,10 +347,10 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
     if (!*flag || !computes) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: device-scope loads below
     switch (nsplit) {
-      case 2: rows_combine<2, TB>(acc, rs, lane_off); break;
-      case 4: rows_combine<4, TB>(acc, rs, lane_off); break;
-      case 8: rows_combine<8, TB>(acc, rs, lane_off); break;
-      default: rows_combine<16, TB>(acc, rs, lane_off); break;
+      case 2: rows_combine<2, TB, TBW>(acc, rs, lane_off, tb0); break;
+      case 4: rows_combine<4, TB, TBW>(acc, rs, lane_off, tb0); break;
+      case 8: rows_combine<8, TB, TBW>(acc, rs, lane_off, tb0); break;
+      default: rows_combine<16, TB, TBW>(acc, rs, lane_off, tb0); break;
     }
   }
   if (!computes) return;
@@ -337,7 +358,7 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
   // ---- rows out: a lane holds tokens 4*(lane>>4)+r of weight row (lane&15) ----
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
-    const int n = n0 + wave * 32 + rb * 16 + (lane & 15);
+    const int n = n0 + (wave & 3) * 32 + rb * 16 + (lane & 15);
     if (n >= a.K) continue;
     float* dst;
     int64_t ld;
@@ -351,10 +372,10 @@ __global__ __launch_bounds__(320, 1) void gemm_w8_rows_kernel(const RowsArgs a) 
       dst = a.y2; ld = a.ld2; col = n - a.k1;
     }
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb)
+    for (int tb = 0; tb < TBW; ++tb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = tb * 16 + 4 * (lane >> 4) + r;
+        const int t = (tb0 + tb) * 16 + 4 * (lane >> 4) + r;
         if (t < a.T) {
           float v = acc[rb][tb][r];
           if (add_res) v += a.residual[(size_t)t * a.ldr + col];
@@ -376,15 +397,16 @@ static int rows_split_choice(int tiles, int nu, int TB, size_t slab_bytes) {
   return S;
 }
 
-template <int TB>
+template <int TB, int PAIR>
 static int launch_rows(const RowsArgs& a, hipStream_t s) {
   static OncePerDevice raised;
   constexpr int lds = rows_lds_bytes<TB>();
   if (raised.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w8_rows_kernel<TB>),
+    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w8_rows_kernel<TB, PAIR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int tiles = (a.K + FR_BN - 1) / FR_BN;
-  hipLaunchKernelGGL((gemm_w8_rows_kernel<TB>), dim3(tiles * a.nsplit), dim3(320), lds, s, a);
+  hipLaunchKernelGGL((gemm_w8_rows_kernel<TB, PAIR>), dim3(tiles * a.nsplit), dim3(64 * (4 * PAIR + 1)), lds, s,
+                     a);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -410,7 +432,7 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
   const int xalign = x_half ? 8 : 4;
   // M % 256: a row's scales then start on a 16-byte boundary
-  if (T > 128 || group_size != 64 || M % 256 != 0 || ldx % xalign != 0 || ((uintptr_t)X % 16) != 0 ||
+  if (T > 192 || group_size != 64 || M % 256 != 0 || ldx % xalign != 0 || ((uintptr_t)X % 16) != 0 ||
       ((uintptr_t)w % 16) != 0 || ((uintptr_t)scales % 16) != 0)
     return KX_EUNSUPPORTED;
   const int tiles = (K + FR_BN - 1) / FR_BN, nu = M / FR_KU;
@@ -431,7 +453,7 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
     X = x16;
     ldx = M;
   }
-  const int TB = T <= 16 ? 1 : T <= 32 ? 2 : T <= 64 ? 4 : T <= 96 ? 6 : 8;
+  const int TB = T <= 16 ? 1 : T <= 32 ? 2 : T <= 64 ? 4 : T <= 96 ? 6 : T <= 128 ? 8 : T <= 160 ? 10 : 12;
   const size_t slab_bytes = have_ws ? split_ws_bytes - kRowsTicketBytes - kRowsX16Bytes : 0;
   int S = rows_split_choice(tiles, nu, TB, slab_bytes);
   if (const char* e = getenv("KX_ROWS_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
@@ -449,11 +471,22 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   a.tickets = reinterpret_cast<unsigned*>(ws);
   a.slabs = have_ws ? reinterpret_cast<float*>(ws + kRowsTicketBytes + kRowsX16Bytes) : nullptr;
   switch (TB) {
-    case 1: return launch_rows<1>(a, s);
-    case 2: return launch_rows<2>(a, s);
-    case 4: return launch_rows<4>(a, s);
-    case 6: return launch_rows<6>(a, s);
-    default: return launch_rows<8>(a, s);
+    case 1: return launch_rows<1, 1>(a, s);
+    case 2: return launch_rows<2, 1>(a, s);
+#ifdef KX_ROWS_NO_PAIRS
+    case 4: return launch_rows<4, 1>(a, s);
+    case 6: return launch_rows<6, 1>(a, s);
+    case 8: return launch_rows<8, 1>(a, s);
+    case 10: return launch_rows<10, 1>(a, s);
+    default: return launch_rows<12, 1>(a, s);
+#else
+    // 64 rows run the same either way (measured); from 96 rows on the paired form is 4-8 % faster
+    case 4: return launch_rows<4, 1>(a, s);
+    case 6: return launch_rows<6, 2>(a, s);
+    case 8: return launch_rows<8, 2>(a, s);
+    case 10: return launch_rows<10, 2>(a, s);
+    default: return launch_rows<12, 2>(a, s);
+#endif
   }
 }
 

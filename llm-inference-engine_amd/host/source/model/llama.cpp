@@ -1077,10 +1077,10 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     // rows: 6.2 / 9.1 / 11.7 ms against 16.9 / 18.4 / 22.4 ms for the int8 single-pass kernel).
     // Which form a prompt takes depends on its length and on that one decision only, never on
     // which prompts came before it.
-    // Up to 128 rows the int8 weights are streamed once against all rows (kx_gemm_w8_rows_f16act):
-    // no fp16 image involved (Llama-3-8B, 16 / 32 / 64 / 96 / 128 rows: 3.2 / 3.6 / 4.6 / 5.6 / 6.4 ms
-    // against 16.4 / 6.0 / 7.0 / 8.3 / 9.0 ms for the tiled kernels).
-    int32_t few_rows_max = 128;
+    // Up to 192 rows the int8 weights are streamed once against all rows (kx_gemm_w8_rows_f16act):
+    // no fp16 image involved (Llama-3-8B, 16 / 32 / 64 / 96 / 128 / 192 rows: 3.2 / 3.6 / 4.6 / 5.6 /
+    // 5.8 / 7.4 ms against 16.4 / 6.0 / 7.0 / 8.3 / 9.0 / 10.7 ms for the tiled kernels).
+    int32_t few_rows_max = 192;
     if (const char* e = getenv("KX_PREFILL_ROWS_MAX")) few_rows_max = atoi(e);  // A/B runs
     const bool few_rows = rows <= few_rows_max && gs == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 &&
                           !getenv("KX_PREFILL_NO_ROWS_KERNEL");  // the switch: A/B runs and tests

@@ -419,7 +419,7 @@ def rmsnorm_f16out(x, weight, eps=1e-5):
 
 
 def gemm_w8_rows(X, w, s, group_size=64, split_ws=None, half=False, k0=None, k1=None, residual=None):
-    """Few-row product (T <= 128): returns Y[T][K], or (y0, y1, y2) when k0/k1 route weight-row ranges.
+    """Few-row product (T <= 192): returns Y[T][K], or (y0, y1, y2) when k0/k1 route weight-row ranges.
     half: hand the rows over as fp16.  split_ws: a zero-filled Buf of kx_gemm_split_workspace_bytes()."""
     K, M = w.shape
     T = X.shape[0]

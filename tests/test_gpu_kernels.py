@@ -569,9 +569,10 @@ def _w8_tol(X, w, s, want):
 @pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("T,K,M", [(2, 384, 1024), (16, 200, 1536), (17, 130, 2304), (33, 640, 512),
                                    (48, 96, 256), (64, 1000, 1280), (65, 300, 768), (96, 257, 1024),
-                                   (100, 130, 2048), (128, 520, 1280)])
+                                   (100, 130, 2048), (128, 520, 1280), (130, 200, 512), (160, 130, 1024),
+                                   (192, 300, 768)])
 def test_gemm_w8_few_rows_vs_oracle(monkeypatch, half, T, K, M):
-    # 2..128 rows against the int8 weight stream: same arithmetic as the tiled int8 kernel (rows rounded
+    # 2..192 rows against the int8 weight stream: same arithmetic as the tiled int8 kernel (rows rounded
     # to fp16, fp32 group sums times fp32 scales); every cut of the reduction gives the bound, the
     # same bits when repeated, and leaves the arrival tickets at zero
     rng = np.random.default_rng(T * 1000 + K + M)
@@ -616,7 +617,7 @@ def test_gemm_w8_few_rows_routing_residual_and_refusals():
     call = lambda T_, M_, gs: kx.lib().kx_gemm_w8_rows_f32(dx.ptr, M_, dw.ptr, ds.ptr, gs, dy.ptr, K, None, 0, None,
                                                            0, K, K, None, 0, T_, M_, K, sp.ptr, sp.nbytes, None)
     # -2 = KX_EUNSUPPORTED
-    assert call(129, M, GS) == -2         # more than 128 rows
+    assert call(193, M, GS) == -2         # more than 192 rows
     assert call(T, 192, GS) == -2         # reduction not a multiple of 256
     assert call(T, M, 128) == -2          # other group sizes
     assert kx.lib().kx_gemm_w8_rows_f32(dx.ptr, M, dw.ptr, ds.ptr, GS, dy.ptr, K, None, 0, None, 0, K, K, None,
@@ -626,7 +627,8 @@ def test_gemm_w8_few_rows_routing_residual_and_refusals():
 @pytest.mark.parametrize("T,K,M,k0,k1", [(48, 6144, 4096, 4096, 5120), (64, 4096, 14336, 4096, 4096),
                                           (24, 28672, 4096, 28672, 28672), (32, 3072, 2048, 2048, 2560),
                                           (128, 4096, 14336, 4096, 4096), (90, 6144, 4096, 4096, 5120),
-                                          (128, 28672, 4096, 28672, 28672)])
+                                          (128, 28672, 4096, 28672, 28672), (192, 4096, 14336, 4096, 4096),
+                                          (150, 6144, 4096, 4096, 5120)])
 def test_gemm_w8_few_rows_full_size(T, K, M, k0, k1):
     # Llama-3-8B (and one Llama-3.2-1B) matrices at full size, checked on a sample of weight rows
     rng = np.random.default_rng(K + M)

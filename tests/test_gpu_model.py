@@ -420,8 +420,8 @@ def test_kept_fp16_weight_images_give_the_same_prompt_results():
     assert np.abs(outs[1][1] - outs[1][4]).max() > 0
 
 
-def test_prompts_up_to_128_rows_stream_the_int8_weights(monkeypatch):
-    # up to 128 rows the prompt pass runs the few-rows kernel on the int8 weights (no fp16 image, with
+def test_prompts_up_to_192_rows_stream_the_int8_weights(monkeypatch):
+    # up to 192 rows the prompt pass runs the few-rows kernel on the int8 weights (no fp16 image, with
     # or without prefill_weight_cache, whatever came before): within the batched-prompt tolerance of
     # one fp32 decode step per row, K/V rows included, same bits when repeated and after a long
     # prompt; the switch back to the tiled kernels stays within the same tolerance
@@ -434,7 +434,7 @@ def test_prompts_up_to_128_rows_stream_the_int8_weights(monkeypatch):
     plain.init_synthetic(31)
     ref = host.Model(seq_len=640, group_size=GS, **shape)
     ref.init_synthetic(31)
-    prompts = {n: rng.integers(0, 1000, n).astype(np.int32) for n in (2, 7, 16, 17, 40, 64, 65, 100, 128)}
+    prompts = {n: rng.integers(0, 1000, n).astype(np.int32) for n in (2, 7, 16, 17, 40, 64, 65, 100, 128, 129, 192)}
     first = {n: plain.prefill(p) for n, p in prompts.items()}
     m.prefill(rng.integers(0, 1000, 520).astype(np.int32))      # a long prompt first: images exist now
     for n, p in prompts.items():
@@ -461,7 +461,7 @@ def test_prompts_up_to_128_rows_stream_the_int8_weights(monkeypatch):
 
 
 def test_short_prompts_use_the_kept_weight_images():
-    # a model that keeps fp16 images of its weights runs prompts of 129..511 rows on the fp16 GEMMs
+    # a model that keeps fp16 images of its weights runs prompts of 193..511 rows on the fp16 GEMMs
     # (with cut reductions: few tiles, many idle CUs) instead of the int8 single-pass kernel, whether
     # or not a long prompt came first; same tolerance against one fp32 decode step per row as the
     # long-prompt form
@@ -474,12 +474,12 @@ def test_short_prompts_use_the_kept_weight_images():
     ref.init_synthetic(31)
     fresh = host.Model(seq_len=640, group_size=GS, prefill_weight_cache=1, **shape)
     fresh.init_synthetic(31)
-    p0 = rng.integers(0, 1000, 200).astype(np.int32)
+    p0 = rng.integers(0, 1000, 250).astype(np.int32)
     first = fresh.prefill(p0)                                    # makes the images on the way
     m.prefill(rng.integers(0, 1000, 520).astype(np.int32))      # images made by a long prompt
     np.testing.assert_array_equal(first, m.prefill(p0))         # same form either way: same bits
     fresh.close()
-    for n in (129, 200, 300):
+    for n in (193, 250, 300):
         p = rng.integers(0, 1000, n).astype(np.int32)
         got = m.prefill(p)
         want = ref.prefill(p, exact=True)

@@ -1,7 +1,7 @@
-"""The few-rows W8A16 product (kx_gemm_w8_rows_f16act) on the four layer matrices of a model, 16 / 32 / 64
-rows: launches back to back on one stream over rotating copies of the weights (more bytes than the
+"""The few-rows W8A16 product (kx_gemm_w8_rows_f16act) on the four layer matrices of a model, 16 / 32 / 64 /
+128 rows: launches back to back on one stream over rotating copies of the weights (more bytes than the
 256 MB cache holds), wall time per launch and the weight bytes per second it amounts to.
-Usage: bench_rows_kernel.py [model] [launches]"""
+Usage: bench_rows_kernel.py [model] [launches] [rows,rows,...]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llm-inference-engine_amd"))
@@ -18,7 +18,8 @@ GS = 64
 lib = kx.lib()
 sp = kx.Buf.zeros(lib.kx_gemm_split_workspace_bytes(), np.uint8)
 rng = np.random.default_rng(1)
-for T in (16, 32, 64):
+row_counts = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [16, 32, 64, 128]
+for T in row_counts:
     total = 0.0
     for label, (K, M) in shapes.items():
         ncopy = max(2, int(600e6 // (K * M)) + 1)
