@@ -1,5 +1,5 @@
 """Prompt pass of Llama-3-8B shapes at 4..768 rows, fp16 weight images resident (a 1024-row prompt
-goes first): the form the engine picks (the few-rows kernel on the int8 weights up to 64 rows, the
+goes first): the form the engine picks (the few-rows kernel on the int8 weights up to 192 rows, the
 fp16 GEMMs above), and beside it the tiled kernels with the few-rows kernel switched off
 (KX_PREFILL_NO_ROWS_KERNEL=1: int8 single-pass below 32 rows, fp16 GEMMs from 32 rows)."""
 import os, sys, time
@@ -13,11 +13,11 @@ model.init_synthetic(1234)
 rng = np.random.default_rng(1)
 model.prefill(rng.integers(0, shape["vocab_size"], 1024).astype(np.int32))  # makes the fp16 images
 model.sync()
-for T in (4, 8, 16, 24, 32, 48, 64, 96, 128, 256, 384, 512, 768):
+for T in (4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 384, 512, 768):
     prompt = rng.integers(0, shape["vocab_size"], T).astype(np.int32)
     line = f"T={T:4d}"
     for tag, off in (("engine", None), ("tiled kernels", "1")):
-        if T > 64 and off:
+        if T > 192 and off:
             continue
         if off:
             os.environ["KX_PREFILL_NO_ROWS_KERNEL"] = off

@@ -11,5 +11,7 @@ cp $O/prof_prefill/p_kernel_stats.csv $P/${R}_prefill_kernel_stats.csv
 cp $O/prefill_mfma.json $P/${R}_prefill_mfma_counters.json
 cp $O/tp.json $P/${R}_tp_rank_compute.json
 cp $O/summary.txt $P/${R}_refresh_summary.txt
+cp $O/short_prompts.txt $P/${R}_short_prompts.txt
+cp $O/few_rows_8b.txt $P/${R}_few_rows_kernel_llama-3-8b.txt
 : > $P/${R}_other_configs.jsonl
 for f in b70 b1 bq bs bkv16 b8k bkv16_8k; do tail -1 $O/$f.json >> $P/${R}_other_configs.jsonl; done

@@ -16,6 +16,8 @@ timeout -k 10 100 python bench.py --kv-dtype f16 $B > $O/bkv16.json 2> /dev/null
 timeout -k 10 100 python bench.py --kv-dtype f16 --context 8192 $B > $O/bkv16_8k.json 2> /dev/null
 timeout -k 10 100 python bench.py --context 8192 $B > $O/b8k.json 2> /dev/null
 timeout -k 10 200 python tools/bench_tp_shapes.py > $O/tp.json
+timeout -k 10 200 python tools/bench_short_prompts.py > $O/short_prompts.txt 2> /dev/null
+timeout -k 10 200 python tools/bench_rows_kernel.py llama-3-8b 60 16,32,64,96,128,192 > $O/few_rows_8b.txt 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python3 $R/bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err
 rm -f $O/prof/b_kernel_trace.csv
