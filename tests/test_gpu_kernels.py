@@ -1028,8 +1028,21 @@ def test_flash_attention_one_dominant_key_per_tile(hs):
         got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0, f16_copies=f16_copies)
         assert np.isfinite(got).all()
         np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
-    last = kx.mha_decode(q[-1].reshape(-1), kc, vc, pos, H, H // KVH, hs, 0)
-    np.testing.assert_allclose(last, want[-1], rtol=0, atol=3e-3)
+    got16 = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0, f16_out=True)
+    np.testing.assert_allclose(got16.astype(np.float32), want, rtol=2.0 ** -10, atol=3e-3)
+    # a 16-bit cache: same data rounded once
+    k16, v16 = kc.astype(np.float16), vc.astype(np.float16)
+    want16 = kxo.flash_attention(q, k16.astype(np.float32), v16.astype(np.float32), H, KVH, hs, S, pos, 0,
+                                 threads=8)
+    got = kx.flash_attention(q, k16, v16, H, KVH, hs, pos, 0, kv16=True)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want16, rtol=0, atol=3e-3)
+    # the decode kernels on the same cache, at positions that end inside different tiles
+    for p_ in (70, 200, 330, pos):
+        one = kx.mha_decode(q[p_].reshape(-1), kc, vc, p_, H, H // KVH, hs, 0)
+        np.testing.assert_allclose(one, want[p_], rtol=0, atol=3e-3)
+        one16 = kx.mha_decode(q[p_].reshape(-1), k16, v16, p_, H, H // KVH, hs, 0, kv16=True)
+        np.testing.assert_allclose(one16, want16[p_], rtol=0, atol=3e-3)
 
 
 # ---------------- 16-bit KV cache ---------------------------------------------------------------------
