@@ -1006,7 +1006,7 @@ def test_flash_attention_forced_rescale_and_last_row_equals_decode():
     np.testing.assert_allclose(got[-1], last, rtol=0, atol=3e-3)
 
 
-@pytest.mark.parametrize("hs", [128, 64])
+@pytest.mark.parametrize("hs", [128, 64, 32])
 def test_flash_attention_one_dominant_key_per_tile(hs):
     # Every 64-key tile holds one key whose score beats everything before it by ~17 (natural log
     # units), at a different position inside each tile.  The tile's running maximum has to be the
