@@ -228,6 +228,29 @@ int kx_gemm_w8_rows_f16act(const void* X16, int64_t ldx, const int8_t* w, const 
                            float* y2, int64_t ld2, int32_t k0, int32_t k1, const float* residual,
                            int64_t ldr, int32_t T, int32_t M, int32_t K, void* split_workspace,
                            size_t split_workspace_bytes, void* stream);
+/* The few-rows product with what follows it in a layer done on the finished totals, in the same
+ * launch (a weight row and its partner -- up row, or the other row of a rotation pair -- are
+ * accumulated by the same lane):
+ * _swiglu_: w13 = [W1; W3] stacked (2H x M); out16[t][h] = fp16(silu(gate) * up), saturating
+ *   (feed_forward's two matmuls + the SwiGLU layer, llama3.cpp:761-776, cuda/swiglu_kernel.cu:4-22).
+ *   H % 64 == 0.
+ * _qkv_rope_: as kx_gemm_w8_f16act_qkv_rope above (attention_qkv + the RoPE layer,
+ *   llama3.cpp:654-677; bias ahead of the rotation, matmul.cpp:76-79): q columns to q[t][ld_q], k
+ *   and v columns to the given rows, q and k rotated for position pos0 + t.  head_size 32, 64 or
+ *   128, q_dim and kv_dim multiples of 128.
+ * Otherwise as kx_gemm_w8_rows_f16act (T <= 192, group size 64, M % 256 == 0);
+ * KX_EUNSUPPORTED for other shapes: run the separate launches. */
+int kx_gemm_w8_rows_swiglu_f16act(const void* X16, int64_t ldx, const int8_t* w13,
+                                  const float* scales13, int32_t group_size, void* out16,
+                                  int64_t ld_out, int32_t T, int32_t M, int32_t H,
+                                  void* split_workspace, size_t split_workspace_bytes, void* stream);
+int kx_gemm_w8_rows_qkv_rope_f16act(const void* X16, int64_t ldx, const int8_t* w, const float* scales,
+                                    int32_t group_size, float* q, int64_t ld_q, float* k, int64_t ld_k,
+                                    float* v, int64_t ld_v, int32_t q_dim, int32_t kv_dim,
+                                    int32_t head_size, int32_t rope_variant, const float* sin_cache,
+                                    const float* cos_cache, int32_t pos0, const float* bias, int32_t T,
+                                    int32_t M, void* split_workspace, size_t split_workspace_bytes,
+                                    void* stream);
 int kx_gemm_f32(const float* X, const float* w, float* Y, int32_t T, int32_t M, int32_t K,
                 void* stream);
 

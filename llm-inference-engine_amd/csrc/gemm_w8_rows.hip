@@ -67,7 +67,32 @@ struct RowsArgs {
   int32_t k0, k1;
   int32_t T, M, K;
   int32_t nsplit;
+  // what follows the product (the launches these replace are named at the entry points)
+  int32_t mode;                 // ROWS_PLAIN, ROWS_SWIGLU, ROWS_QKV_ROPE
+  _Float16* h16; int64_t ldh;   // ROWS_SWIGLU: fp16 rows out, silu(gate) * up
+  int32_t half;                 //   gate rows [0, half), up rows [half, 2 half)
+  const float* sin_cache; const float* cos_cache; const float* bias;  // ROWS_QKV_ROPE
+  int32_t head_size, rope_variant, pos0;
 };
+enum { ROWS_PLAIN = 0, ROWS_SWIGLU = 1, ROWS_QKV_ROPE = 2 };
+
+// Which weight rows a compute wave's ring holds: row(rb, i) = base + i * istep + rb * rbstep for row
+// block rb (0, 1) and index i (0..15).  A lane ends up with the totals of rows (0, i) and (1, i) for
+// its tokens, so the fused forms put the two rows that meet in the epilogue there: a gate row and
+// its up row, or the two rows of a rotation pair (neighbours, or half a head apart).
+struct RowsMap { int base, istep, rbstep; };
+__device__ __forceinline__ RowsMap rows_map(const RowsArgs& a, int tile, int w) {
+  if (a.mode == ROWS_SWIGLU) return {tile * 64 + w * 16, 1, a.half};
+  const int n0 = tile * 128;
+  if (a.mode == ROWS_QKV_ROPE && n0 < a.k1) {
+    if (a.rope_variant == KX_ROPE_HALF_SPLIT) {
+      const int P = a.head_size >> 1, c = w * 16;
+      return {n0 + (c / P) * a.head_size + c % P, 1, P};
+    }
+    return {n0 + w * 32, 2, 1};
+  }
+  return {n0 + w * 32, 1, 16};
+}
 
 // four int8 -> four fp16 (two packed pairs), exact
 __device__ __forceinline__ void cvt_w8x4(uint32_t d, uint32_t& lo, uint32_t& hi) {
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nsplit = a.nsplit;
   const int part = blockIdx.x % nsplit, tile = blockIdx.x / nsplit;
-  const int n0 = tile * FR_BN;
+  const RowsMap map = rows_map(a, tile, wave & 3);
   // this part's units [u0, u0 + un)
   int u0, un;
   {
@@ -224,12 +249,12 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
       for (int h = 0; h < 2; ++h) {
         const int r8 = lane >> 3, key = h * 4 + (r8 >> 1);
         // rows past the end re-read the last row; their results are never stored
-        const unsigned n = (unsigned)min(n0 + (wave & 3) * 32 + rb * 16 + h * 8 + r8, a.K - 1);
+        const unsigned n = (unsigned)min(map.base + (h * 8 + r8) * map.istep + rb * map.rbstep, a.K - 1);
         woff[rb][h] = n * (unsigned)a.M + (unsigned)u0 * FR_KU + (unsigned)(((lane & 7) ^ key) * 16);
       }
     {
       // lanes 0-31: the rows' first 16 bytes of a four-unit block of scales, lanes 32-63: the second
-      const unsigned n = (unsigned)min(n0 + (wave & 3) * 32 + (lane & 31), a.K - 1);
+      const unsigned n = (unsigned)min(map.base + (lane & 15) * map.istep + ((lane >> 4) & 1) * map.rbstep, a.K - 1);
       soff = n * (unsigned)(a.M / 64) * 4u + (unsigned)(lane >> 5) * 16u;
     }
     const char* const wbase = reinterpret_cast<const char*>(a.w);
@@ -355,10 +380,59 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
   }
   if (!computes) return;
 
-  // ---- rows out: a lane holds tokens 4*(lane>>4)+r of weight row (lane&15) ----
+  // ---- rows out: a lane holds tokens 4*(lane>>4)+r of the rows (rb, lane&15) of its wave ----
+  const int row0 = map.base + (lane & 15) * map.istep, row1 = row0 + map.rbstep;
+  if (a.mode == ROWS_SWIGLU) {
+    // swiglu_kernel_cu_fp32 (cuda/swiglu_kernel.cu:4-22) on the finished gate / up totals
+#pragma unroll
+    for (int tb = 0; tb < TBW; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = (tb0 + tb) * 16 + 4 * (lane >> 4) + r;
+        if (t < a.T) {
+          const float g = acc[0][tb][r], u = acc[1][tb][r];
+          a.h16[(size_t)t * a.ldh + row0] = sat_f16(g * (1.0f / (1.0f + expf(-g))) * u);
+        }
+      }
+    return;
+  }
+  if (a.mode == ROWS_QKV_ROPE) {
+    // bias ahead of the rotation (matmul.cpp:76-79), rope_kernel_cu (cuda/rope_kernel.cu:17-34 half
+    // split, :111-127 interleaved) for position pos0 + t on q and k rows; v rows get their bias only
+    const bool rotate = row0 < a.k1;
+    float* dst;
+    int64_t ld;
+    int c0;
+    if (row0 < a.k0) { dst = a.y0; ld = a.ld0; c0 = row0; }
+    else if (row0 < a.k1) { dst = a.y1; ld = a.ld1; c0 = row0 - a.k0; }
+    else { dst = a.y2; ld = a.ld2; c0 = row0 - a.k1; }
+    const int c1 = c0 + map.rbstep;
+    const float b0 = a.bias ? a.bias[row0] : 0.f, b1 = a.bias ? a.bias[row1] : 0.f;
+    const int in_head = row0 % a.head_size;
+    const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
+#pragma unroll
+    for (int tb = 0; tb < TBW; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = (tb0 + tb) * 16 + 4 * (lane >> 4) + r;
+        if (t < a.T) {
+          float o0 = acc[0][tb][r] + b0, o1 = acc[1][tb][r] + b1;
+          if (rotate) {
+            const size_t ti = (size_t)(a.pos0 + t) * a.head_size + tab;
+            const float fci = a.sin_cache[ti], fcr = a.cos_cache[ti];
+            const float t0 = o0 * fcr - o1 * fci;
+            o1 = o0 * fci + o1 * fcr;
+            o0 = t0;
+          }
+          dst[(size_t)t * ld + c0] = o0;
+          dst[(size_t)t * ld + c1] = o1;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
-    const int n = n0 + (wave & 3) * 32 + rb * 16 + (lane & 15);
+    const int n = rb ? row1 : row0;
     if (n >= a.K) continue;
     float* dst;
     int64_t ld;
@@ -404,7 +478,7 @@ static int launch_rows(const RowsArgs& a, hipStream_t s) {
   if (raised.first())
     KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w8_rows_kernel<TB, PAIR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int tiles = (a.K + FR_BN - 1) / FR_BN;
+  const int tiles = a.mode == ROWS_SWIGLU ? a.half / 64 : (a.K + FR_BN - 1) / FR_BN;
   hipLaunchKernelGGL((gemm_w8_rows_kernel<TB, PAIR>), dim3(tiles * a.nsplit), dim3(64 * (4 * PAIR + 1)), lds, s,
                      a);
   KX_LAUNCH_CHECK();
@@ -425,8 +499,10 @@ __global__ void rows_f32_to_f16_kernel(const float* __restrict__ x, int64_t ldx,
 static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, const float* scales,
                     int32_t group_size, float* y0, int64_t ld0, float* y1, int64_t ld1, float* y2, int64_t ld2,
                     int32_t k0, int32_t k1, const float* residual, int64_t ldr, int32_t T, int32_t M, int32_t K,
-                    void* split_ws, size_t split_ws_bytes, hipStream_t s) {
-  if (!X || !w || !scales || !y0 || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
+                    void* split_ws, size_t split_ws_bytes, hipStream_t s, const RowsArgs* fused = nullptr) {
+  const int mode = fused ? fused->mode : ROWS_PLAIN;
+  if (!X || !w || !scales || T <= 0 || M <= 0 || K <= 0 || group_size <= 0) return KX_EINVAL;
+  if (!y0 && mode != ROWS_SWIGLU) return KX_EINVAL;
   if (!y1 && !y2) { k0 = K; k1 = K; }
   if (k0 < 0 || k1 < k0 || k1 > K) return KX_EINVAL;
   if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
@@ -468,6 +544,12 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   a.ldx = ldx; a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
   a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
   a.nsplit = S;
+  if (fused) {
+    a.mode = fused->mode;
+    a.h16 = fused->h16; a.ldh = fused->ldh; a.half = fused->half;
+    a.sin_cache = fused->sin_cache; a.cos_cache = fused->cos_cache; a.bias = fused->bias;
+    a.head_size = fused->head_size; a.rope_variant = fused->rope_variant; a.pos0 = fused->pos0;
+  }
   a.tickets = reinterpret_cast<unsigned*>(ws);
   a.slabs = have_ws ? reinterpret_cast<float*>(ws + kRowsTicketBytes + kRowsX16Bytes) : nullptr;
   switch (TB) {
@@ -508,4 +590,38 @@ extern "C" int kx_gemm_w8_rows_f16act(const void* X16, int64_t ldx, const int8_t
                                       size_t split_workspace_bytes, void* stream) {
   return kx::rows_run(X16, true, ldx, w, scales, group_size, y0, ld0, y1, ld1, y2, ld2, k0, k1, residual, ldr,
                       T, M, K, split_workspace, split_workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int kx_gemm_w8_rows_swiglu_f16act(const void* X16, int64_t ldx, const int8_t* w13, const float* scales13,
+                                             int32_t group_size, void* out16, int64_t ld_out, int32_t T, int32_t M,
+                                             int32_t H, void* split_workspace, size_t split_workspace_bytes,
+                                             void* stream) {
+  if (!out16 || H <= 0 || ld_out < H) return KX_EINVAL;
+  if (H % 64 != 0 || ((uintptr_t)out16 % 2) != 0) return KX_EUNSUPPORTED;
+  kx::RowsArgs f{};
+  f.mode = kx::ROWS_SWIGLU;
+  f.h16 = static_cast<_Float16*>(out16); f.ldh = ld_out; f.half = H;
+  return kx::rows_run(X16, true, ldx, w13, scales13, group_size, nullptr, 0, nullptr, 0, nullptr, 0, 2 * H, 2 * H,
+                      nullptr, 0, T, M, 2 * H, split_workspace, split_workspace_bytes, (hipStream_t)stream, &f);
+}
+
+extern "C" int kx_gemm_w8_rows_qkv_rope_f16act(const void* X16, int64_t ldx, const int8_t* w, const float* scales,
+                                               int32_t group_size, float* q, int64_t ld_q, float* k, int64_t ld_k,
+                                               float* v, int64_t ld_v, int32_t q_dim, int32_t kv_dim,
+                                               int32_t head_size, int32_t rope_variant, const float* sin_cache,
+                                               const float* cos_cache, int32_t pos0, const float* bias, int32_t T,
+                                               int32_t M, void* split_workspace, size_t split_workspace_bytes,
+                                               void* stream) {
+  if (!q || !k || !v || !sin_cache || !cos_cache || q_dim <= 0 || kv_dim <= 0 || pos0 < 0) return KX_EINVAL;
+  if (rope_variant != KX_ROPE_INTERLEAVED && rope_variant != KX_ROPE_HALF_SPLIT) return KX_EINVAL;
+  // whole 128-row tiles of one kind (q, k or v), rotation pairs inside a wave's 32 rows
+  if ((head_size != 32 && head_size != 64 && head_size != 128) || q_dim % 128 != 0 || kv_dim % 128 != 0)
+    return KX_EUNSUPPORTED;
+  kx::RowsArgs f{};
+  f.mode = kx::ROWS_QKV_ROPE;
+  f.sin_cache = sin_cache; f.cos_cache = cos_cache; f.bias = bias;
+  f.head_size = head_size; f.rope_variant = rope_variant; f.pos0 = pos0;
+  return kx::rows_run(X16, true, ldx, w, scales, group_size, q, ld_q, k, ld_k, v, ld_v, q_dim, q_dim + kv_dim,
+                      nullptr, 0, T, M, q_dim + 2 * kv_dim, split_workspace, split_workspace_bytes,
+                      (hipStream_t)stream, &f);
 }

@@ -1084,6 +1084,11 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     if (const char* e = getenv("KX_PREFILL_ROWS_MAX")) few_rows_max = atoi(e);  // A/B runs
     const bool few_rows = rows <= few_rows_max && gs == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 &&
                           !getenv("KX_PREFILL_NO_ROWS_KERNEL");  // the switch: A/B runs and tests
+    // SwiGLU, and bias + RoPE + K/V placement, ride in the few-rows products' launches where the shapes
+    // allow (whole 128-row tiles of q, k and v rows); KX_PREFILL_ROWS_UNFUSED: A/B runs and tests
+    const bool rows_fused = few_rows && !getenv("KX_PREFILL_ROWS_UNFUSED");
+    const bool rows_fused_rope = rows_fused && ql % 128 == 0 && kl % 128 == 0 &&
+                                 (c.head_size == 32 || c.head_size == 64 || c.head_size == 128);
     if (!few_rows && f16_ok && rows >= 32) ST_RET(reserve_weight_images());
     int32_t f16_min_rows = weight_images_ == 1 ? 32 : 512;
     if (const char* e = getenv("KX_PREFILL_F16_MIN_ROWS")) f16_min_rows = atoi(e);  // A/B runs
@@ -1106,17 +1111,29 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
                                         y2, ld2, k0, k1, resid, dim, rows, Mm, Kk, split_ws, split_ws_bytes, st);
         };
         KX_RET(kx_rmsnorm_f16out(X, lw.attn_norm, XN, dim, rows, c.rms_eps, st));
-        KX_RET(rows_gemm(XN, dim, lw.qkv, Q, ql, krow, kl, vrow, kl, ql, ql + kl, nullptr, dim, lw.qkv.rows));
-        KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
-                                p0, rows, sin_, cos_, st));
+        if (rows_fused_rope) {
+          // bias, RoPE and the K/V row placement on the finished totals, in the product's launch
+          KX_RET(kx_gemm_w8_rows_qkv_rope_f16act(XN, dim, static_cast<const int8_t*>(lw.qkv.w), lw.qkv.s, gs, Q, ql,
+                                                 krow, kl, vrow, kl, ql, kl, c.head_size, c.rope_variant, sin_,
+                                                 cos_, p0, bq, rows, dim, split_ws, split_ws_bytes, st));
+        } else {
+          KX_RET(rows_gemm(XN, dim, lw.qkv, Q, ql, krow, kl, vrow, kl, ql, ql + kl, nullptr, dim, lw.qkv.rows));
+          KX_RET(kx_rope_bias_f32(c.rope_variant, ql, kl, c.head_size, Q, krow, kl, vrow, kl, bq, bk, bv,
+                                  p0, rows, sin_, cos_, st));
+        }
         if (c.kv_f16) KX_RET(file_kv16(k_ptr, v_ptr, p0, rows));
         KX_RET(attention(nullptr, ATT, rows, p0 + rows - 1, l));
         KX_RET(rows_gemm(ATT, ql, lw.wo, X, dim, nullptr, 0, nullptr, 0, dim, dim, res, ql, dim));
         ST_RET(all_reduce(X, (size_t)rows * dim));
         KX_RET(kx_rmsnorm_f16out(X, lw.ffn_norm, XN, dim, rows, c.rms_eps, st));
-        KX_RET(rows_gemm(XN, dim, lw.w13, H13, 2 * hl, nullptr, 0, nullptr, 0, 2 * hl, 2 * hl, nullptr, dim,
-                         2 * hl));
-        KX_RET(kx_swiglu_rows_f16out(H13, 2 * hl, hl, HH, hl, rows, st));
+        if (rows_fused) {
+          KX_RET(kx_gemm_w8_rows_swiglu_f16act(XN, dim, static_cast<const int8_t*>(lw.w13.w), lw.w13.s, gs, HH, hl,
+                                               rows, dim, hl, split_ws, split_ws_bytes, st));
+        } else {
+          KX_RET(rows_gemm(XN, dim, lw.w13, H13, 2 * hl, nullptr, 0, nullptr, 0, 2 * hl, 2 * hl, nullptr, dim,
+                           2 * hl));
+          KX_RET(kx_swiglu_rows_f16out(H13, 2 * hl, hl, HH, hl, rows, st));
+        }
         KX_RET(rows_gemm(HH, hl, lw.w2, X, dim, nullptr, 0, nullptr, 0, dim, dim, res, hl, dim));
         ST_RET(all_reduce(X, (size_t)rows * dim));
         continue;

@@ -81,6 +81,11 @@ SIGNATURES = {
     "kx_gemm_w8_rows_f16act": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
                                          C.c_int64, _i32, _i32, _vp, C.c_int64, _i32, _i32, _i32, _vp, _sz,
                                          _vp]),
+    "kx_gemm_w8_rows_swiglu_f16act": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _i32, _i32, _i32,
+                                                _vp, _sz, _vp]),
+    "kx_gemm_w8_rows_qkv_rope_f16act": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64,
+                                                  _vp, C.c_int64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
+                                                  _i32, _i32, _vp, _sz, _vp]),
     "kx_rmsnorm_f16out": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_flash_attention_f16out": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                             _i32, _f, _i32, _vp, _sz, _vp]),

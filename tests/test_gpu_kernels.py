@@ -647,6 +647,94 @@ def test_gemm_w8_few_rows_full_size(T, K, M, k0, k1):
     assert not sp.numpy()[:4096].any()
 
 
+@pytest.mark.parametrize("T,M,H", [(5, 512, 128), (40, 768, 320), (64, 256, 64), (100, 1024, 192), (192, 512, 256)])
+def test_gemm_w8_few_rows_swiglu_in_the_epilogue(monkeypatch, T, M, H):
+    # [W1; W3] product and SwiGLU in one launch: fp16(silu(gate) * up) of the plain few-rows product's
+    # totals -- the same bits, whichever way the reduction is cut
+    rng = np.random.default_rng(T + M + H)
+    L = kx.lib()
+    _, w, s = rand_w8(rng, 2 * H, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    sp = kx.Buf.zeros(L.kx_gemm_split_workspace_bytes(), np.uint8)
+    dx, dw, dsc = kx.Buf.from_numpy(X16), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)
+    for parts in ("", "1", "2", "4"):
+        if parts and M // 128 < int(parts):
+            continue
+        if parts:
+            monkeypatch.setenv("KX_ROWS_SPLIT", parts)
+        else:
+            monkeypatch.delenv("KX_ROWS_SPLIT", raising=False)
+        plain = kx.gemm_w8_rows(X16.astype(np.float32), w, s, GS, split_ws=sp, half=True)
+        g, u = plain[:, :H], plain[:, H:]
+        with np.errstate(over="ignore"):
+            want = (g * (np.float32(1.0) / (np.float32(1.0) + np.exp(-g))) * u).astype(np.float32)
+        out = kx.Buf.from_numpy(np.full((T, H + 8), 3.0, np.float16))   # rows wider than H: padding untouched
+        kx.check(L.kx_gemm_w8_rows_swiglu_f16act(dx.ptr, M, dw.ptr, dsc.ptr, GS, out.ptr, H + 8, T, M, H, sp.ptr,
+                                                 sp.nbytes, None))
+        kx.sync()
+        got = out.numpy(np.float16, (T, H + 8))
+        assert np.all(got[:, H:] == np.float16(3.0))
+        # expf on the device against numpy's exp: an ulp or two in fp32, then one fp16 rounding
+        np.testing.assert_allclose(got[:, :H].astype(np.float32), want, rtol=2.0 ** -10, atol=1e-6, err_msg=parts)
+    assert not sp.numpy()[:4096].any()
+    assert L.kx_gemm_w8_rows_swiglu_f16act(dx.ptr, M, dw.ptr, dsc.ptr, GS, out.ptr, 96, T, M, 96, sp.ptr,
+                                           sp.nbytes, None) == -2   # H not a multiple of 64
+
+
+@pytest.mark.parametrize("hs,variant,T,pos0,with_bias", [(128, 1, 100, 5, False), (64, 1, 192, 0, True),
+                                                         (64, 0, 33, 17, True), (128, 0, 16, 3, False),
+                                                         (32, 1, 70, 2, True), (32, 0, 7, 0, False)])
+def test_gemm_w8_few_rows_qkv_with_bias_and_rope_in_the_epilogue(monkeypatch, hs, variant, T, pos0, with_bias):
+    # one launch = few-rows product + bias + rotary embedding + q / K-row / V-row placement, against the
+    # plain few-rows product followed by the oracle's bias-then-rope
+    rng = np.random.default_rng(hs + T)
+    L = kx.lib()
+    M, H, KVH = 512, 8, 4
+    ql, kl = H * hs, KVH * hs
+    K = ql + 2 * kl
+    _, w, s = rand_w8(rng, K, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    bias = rng.standard_normal(K).astype(np.float32) * 0.1 if with_bias else None
+    S = pos0 + T + 3
+    ds_, dc_ = kx.Buf.zeros((S, hs)), kx.Buf.zeros((S, hs))
+    kx.check(L.kx_sin_cos_cache_f32(hs, S, 10000.0, ds_.ptr, dc_.ptr, None))
+    s_tab, c_tab = ds_.numpy(), dc_.numpy()
+    sp = kx.Buf.zeros(L.kx_gemm_split_workspace_bytes(), np.uint8)
+    plain = kx.gemm_w8_rows(X16.astype(np.float32), w, s, GS, split_ws=sp, half=True)
+    if with_bias:
+        plain = plain + bias
+    dx, dw, dsc = kx.Buf.from_numpy(X16), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)
+    db = kx.Buf.from_numpy(bias) if with_bias else None
+    kst = kl + 64                                       # K / V rows live in a wider cache
+    for parts in ("", "2"):
+        if parts:
+            monkeypatch.setenv("KX_ROWS_SPLIT", parts)
+        q = kx.Buf.zeros((T, ql))
+        kc = kx.Buf.from_numpy(np.full((S, kst), 7.0, np.float32))
+        vc = kx.Buf.from_numpy(np.full((S, kst), 9.0, np.float32))
+        kx.check(L.kx_gemm_w8_rows_qkv_rope_f16act(dx.ptr, M, dw.ptr, dsc.ptr, GS, q.ptr, ql, kc.at(pos0 * kst * 4),
+                                                   kst, vc.at(pos0 * kst * 4), kst, ql, kl, hs, variant, ds_.ptr,
+                                                   dc_.ptr, pos0, db.ptr if db else None, T, M, sp.ptr, sp.nbytes,
+                                                   None))
+        kx.sync()
+        gq, gk, gv = q.numpy(), kc.numpy(), vc.numpy()
+        tol = 2e-5 * np.abs(plain).max()
+        for r in range(T):
+            wq, wk = kxo.rope(variant, ql, kl, hs, plain[r, :ql].copy(), plain[r, ql:ql + kl].copy(), pos0 + r,
+                              s_tab, c_tab)
+            np.testing.assert_allclose(gq[r], wq, rtol=1e-5, atol=tol)
+            np.testing.assert_allclose(gk[pos0 + r, :kl], wk, rtol=1e-5, atol=tol)
+            np.testing.assert_allclose(gv[pos0 + r, :kl], plain[r, ql + kl:], rtol=1e-6, atol=tol)
+        # rows outside the chunk and the padding beside the rows are untouched
+        assert np.all(gk[:pos0] == 7.0) and np.all(gk[pos0 + T:] == 7.0) and np.all(gk[:, kl:] == 7.0)
+        assert np.all(gv[:pos0] == 9.0) and np.all(gv[pos0 + T:] == 9.0) and np.all(gv[:, kl:] == 9.0)
+    assert not sp.numpy()[:4096].any()
+    # dimensions that are not whole 128-row tiles are refused, not mangled
+    assert L.kx_gemm_w8_rows_qkv_rope_f16act(dx.ptr, M, dw.ptr, dsc.ptr, GS, q.ptr, ql, kc.ptr, kst, vc.ptr, kst,
+                                             ql - 64, kl + 32, hs, variant, ds_.ptr, dc_.ptr, 0, None, T, M, sp.ptr,
+                                             sp.nbytes, None) == -2
+
+
 def test_swiglu_rows_fp16_result():
     rng = np.random.default_rng(3)
     T, half = 37, 1024

@@ -452,6 +452,13 @@ def test_prompts_up_to_192_rows_stream_the_int8_weights(monkeypatch):
         assert m.state()[1] == n
         m.decode(3, use_graph=False)
         ref.decode(3, use_graph=False)
+    # SwiGLU and bias + RoPE as launches of their own instead of the products' epilogues: the same
+    # formulas on the same totals
+    monkeypatch.setenv("KX_PREFILL_ROWS_UNFUSED", "1")
+    for n in (7, 40, 100, 192):
+        got = plain.prefill(prompts[n])
+        assert np.abs(got - first[n]).max() <= 1e-5 * np.abs(first[n]).max(), n
+    monkeypatch.delenv("KX_PREFILL_ROWS_UNFUSED")
     monkeypatch.setenv("KX_PREFILL_NO_ROWS_KERNEL", "1")
     for n in (16, 40):
         got = plain.prefill(prompts[n])
