@@ -286,14 +286,45 @@ def main():
     kv16 = args.kv_dtype == "f16"
     model = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, kv_f16=kv16, **shape)
     model.init_synthetic(1234)
-    def connect_peers():
+    # Peer-mailbox set-up in stages that end with the ranks agreeing on whether ALL of them got
+    # through (a gloo all-reduce of a flag), so a rank that fails never leaves the others inside a
+    # collective it will not join: either every rank goes on, or every rank drops the mailboxes.
+    def all_ok(stage):
+        ok, err = 1.0, None
+        try:
+            stage()
+        except kx.KxError as e:
+            ok, err = 0.0, str(e)
+        t = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.item() > 0, err
+
+    def peer_setup():
+        """None when every rank is connected to every mailbox, else what went wrong."""
+        state = {}
+
+        def create():
+            state["handle"] = model.peer_create(max(shape["dim"], 2 * world))
+
+        def connect():
+            model.peer_connect(state["handles"])
+
+        ok, err = all_ok(create)
+        if not ok:
+            return err or "peer-mailbox creation failed on another rank"
         handles = [None] * world
-        dist.all_gather_object(handles, model.peer_create(max(shape["dim"], 2 * world)))
-        model.peer_connect(handles)
-        dist.barrier()
+        dist.all_gather_object(handles, state["handle"])
+        state["handles"] = handles
+        ok, err = all_ok(connect)
+        if not ok:
+            model.peer_disable()
+            return err or "peer-mailbox connection failed on another rank"
+        return None
 
     if world > 1 and args.one_gpu_rehearsal:
-        connect_peers()
+        err = peer_setup()
+        if err:
+            sys.exit(f"[bench] rehearsal needs the peer mailboxes: {err}")
     elif world > 1:
         ids = [host.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -390,28 +421,43 @@ def main():
         # peer-mailbox collectives on the compute stream (kx_peer_*) instead of RCCL calls on the
         # side stream.  Every rank takes part; the figure counts only when no rank's wait gave up.
         peer = None
-        if not args.no_peer and not args.one_gpu_rehearsal:
-            try:
-                connect_peers()
-                # pre-flight: two eager reduces; a rank whose wait gave up (4 s) calls the run off
+        if not args.no_peer:
+            state = {}
+
+            def preflight():
+                # two eager reduces; a rank whose wait gave up (4 s) calls the run off
                 model.profile_allreduce(shape["dim"], 1)
-                t = torch.tensor([float(model.peer_timed_out())], dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                if t.item() > 0:
-                    model.peer_disable()
+                if model.peer_timed_out():
                     raise kx.KxError("peer-mailbox pre-flight: a wait timed out")
+
+            def token_loop():
+                # no barrier in here: a rank that fails must reach the agreement, not leave the
+                # others waiting; the ranks start together behind the previous agreement
                 model.set_state(start_token, start_pos)
                 model.decode(max(args.warmup, 2), use_graph=use_graph)
-                fence()
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 model.decode(args.steps, use_graph=use_graph)
-                fence()
-                t = torch.tensor([time.perf_counter() - t0, float(model.peer_timed_out())], dtype=torch.float64)
+                torch.cuda.synchronize()
+                state["elapsed"] = time.perf_counter() - t0
+                state["allreduce_us"] = model.profile_allreduce(shape["dim"], 200) * 1e3
+
+            def run_peer():
+                # (a rehearsal connected its mailboxes at the start: it has no other collective)
+                err = None if args.one_gpu_rehearsal else peer_setup()
+                if err:
+                    return {"error": err}
+                for stage in (preflight, token_loop):
+                    ok, err = all_ok(stage)
+                    if not ok:
+                        model.peer_disable()
+                        return {"error": err or f"peer-mailbox {stage.__name__} failed on another rank"}
+                t = torch.tensor([state["elapsed"], float(model.peer_timed_out())], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                peer = {"elapsed_s": float(t[0].item()), "timed_out": bool(t[1].item() > 0),
-                        "allreduce_us": model.profile_allreduce(shape["dim"], 200) * 1e3}
-            except kx.KxError as e:
-                peer = {"error": str(e)}
+                return {"elapsed_s": float(t[0].item()), "timed_out": bool(t[1].item() > 0),
+                        "allreduce_us": state["allreduce_us"]}
+
+            peer = run_peer()
             fence()
             if comm is not None:
                 comm["peer_mailbox"] = peer
@@ -432,7 +478,8 @@ def main():
                 pm["tok_per_s"] = args.steps / pm["elapsed_s"]
                 if pm["tok_per_s"] > tok_s:  # the headline is the faster of the two measured token loops
                     elapsed, tok_s = pm["elapsed_s"], pm["tok_per_s"]
-                    collective = "peer-mailbox all-reduce, one launch on the compute stream"
+                    if not args.one_gpu_rehearsal:
+                        collective = "peer-mailbox all-reduce, one launch on the compute stream"
         if args.model == "llama-3-8b" and world == 1:
             traffic, traffic_src = measured_traffic()
             if traffic is not None:
