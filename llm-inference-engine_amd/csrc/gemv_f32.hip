@@ -1,7 +1,7 @@
 // fp32 GEMV for gfx950: y = (W[K][M] . x) * scale.
 // Stands in for matmul_kernel_cu_fp32 (kuiper/source/op/kernels/cuda/matmul_kernel.cu:6-54) and
 // matmul_kernel_cpu (cpu/matmul_kernel.cpp:5-41).  One wavefront per row, 128-bit loads
-// (256 floats per wave instruction), x staged once per workgroup in LDS, DPP/swizzle reduce.
+// (256 floats per wave instruction), x staged once per workgroup in LDS, DPP / permlane-swap reduce.
 #include "kx_common.hpp"
 
 namespace kx {

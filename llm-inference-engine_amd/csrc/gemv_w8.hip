@@ -8,7 +8,7 @@
 // issues 128-bit non-temporal loads of 16 consecutive int8 (1 KiB per wave instruction, fully
 // coalesced), the 16 elements of a lane always sit inside one quant group so its scale is one
 // register, x is staged once per workgroup in LDS in a layout that makes the four 16-byte
-// reads per weight load conflict-free, and the row sum is finished with DPP + swizzle.
+// reads per weight load conflict-free, and the row sum is finished with DPP + permlane swaps.
 // The first batch of weight loads is issued before x is staged so the HBM round trip and the
 // L2 round trip for x overlap; bias, residual and rotation operands are requested before the
 // chunk loop so no dependent load is left for the tail.
