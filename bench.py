@@ -236,6 +236,23 @@ def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
     }
 
 
+def stage_agreed(dist, stage, errors=(Exception,)):
+    """Runs stage() on this rank, then has the ranks agree (an all-reduce of a flag) on whether ALL
+    of them got through it: (True, None) everywhere, or (False, this rank's own error or None)
+    everywhere.  A rank that fails therefore never leaves the others inside a collective it will
+    not join: either every rank goes on to the next stage, or every rank gives the path up.
+    stage() itself must not contain a collective that a failed rank would miss."""
+    import torch
+    ok, err = 1.0, None
+    try:
+        stage()
+    except errors as e:
+        ok, err = 0.0, str(e)
+    t = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.item() > 0, err
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,18 +303,8 @@ def main():
     kv16 = args.kv_dtype == "f16"
     model = host.Model(seq_len=seq_len, group_size=64, tp_size=world, tp_rank=rank, kv_f16=kv16, **shape)
     model.init_synthetic(1234)
-    # Peer-mailbox set-up in stages that end with the ranks agreeing on whether ALL of them got
-    # through (a gloo all-reduce of a flag), so a rank that fails never leaves the others inside a
-    # collective it will not join: either every rank goes on, or every rank drops the mailboxes.
     def all_ok(stage):
-        ok, err = 1.0, None
-        try:
-            stage()
-        except kx.KxError as e:
-            ok, err = 0.0, str(e)
-        t = torch.tensor([ok], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return t.item() > 0, err
+        return stage_agreed(dist, stage, kx.KxError)
 
     def peer_setup():
         """None when every rank is connected to every mailbox, else what went wrong."""
