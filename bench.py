@@ -23,6 +23,10 @@ import time
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: without this, sharing device memory across
+# processes (RCCL, the peer mailboxes) fails in hipIpcGetMemHandle; must be set before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
