@@ -735,6 +735,51 @@ def test_gemm_w8_few_rows_qkv_with_bias_and_rope_in_the_epilogue(monkeypatch, hs
                                              sp.nbytes, None) == -2
 
 
+def test_gemm_w8_few_rows_fused_forms_full_size():
+    # Llama-3-8B's W1|W3 and Wq|Wk|Wv at full size, 128 rows: the fused epilogues on the totals of the
+    # plain few-rows product (itself checked against the oracle at these sizes above)
+    rng = np.random.default_rng(5)
+    L = kx.lib()
+    sp = kx.Buf.zeros(L.kx_gemm_split_workspace_bytes(), np.uint8)
+    T, M, H = 128, 4096, 14336
+    _, w, s = rand_w8(rng, 2 * H, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    dx, dw, dsc = kx.Buf.from_numpy(X16), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s)
+    plain = kx.gemm_w8_rows(X16.astype(np.float32), w, s, GS, split_ws=sp, half=True)
+    g, u = plain[:, :H], plain[:, H:]
+    with np.errstate(over="ignore"):
+        want = g * (np.float32(1.0) / (np.float32(1.0) + np.exp(-g))) * u
+    out = kx.Buf.zeros((T, H), np.float16)
+    kx.check(L.kx_gemm_w8_rows_swiglu_f16act(dx.ptr, M, dw.ptr, dsc.ptr, GS, out.ptr, H, T, M, H, sp.ptr, sp.nbytes,
+                                             None))
+    kx.sync()
+    np.testing.assert_allclose(out.numpy(np.float16, (T, H)).astype(np.float32), want, rtol=2.0 ** -10, atol=1e-6)
+    del dw, dsc, w, s
+    hs, ql, kl, pos0 = 128, 4096, 1024, 4000
+    K = ql + 2 * kl
+    _, w, s = rand_w8(rng, K, M)
+    bias = (rng.standard_normal(K) * 0.1).astype(np.float32)
+    S = pos0 + T
+    ds_, dc_ = kx.Buf.zeros((S, hs)), kx.Buf.zeros((S, hs))
+    kx.check(L.kx_sin_cos_cache_f32(hs, S, 500000.0, ds_.ptr, dc_.ptr, None))
+    s_tab, c_tab = ds_.numpy(), dc_.numpy()
+    plain = kx.gemm_w8_rows(X16.astype(np.float32), w, s, GS, split_ws=sp, half=True) + bias
+    dw, dsc, db = kx.Buf.from_numpy(w), kx.Buf.from_numpy(s), kx.Buf.from_numpy(bias)
+    q, kc, vc = kx.Buf.zeros((T, ql)), kx.Buf.zeros((T, kl)), kx.Buf.zeros((T, kl))
+    kx.check(L.kx_gemm_w8_rows_qkv_rope_f16act(dx.ptr, M, dw.ptr, dsc.ptr, GS, q.ptr, ql, kc.ptr, kl, vc.ptr, kl, ql,
+                                               kl, hs, 1, ds_.ptr, dc_.ptr, pos0, db.ptr, T, M, sp.ptr, sp.nbytes,
+                                               None))
+    kx.sync()
+    gq, gk, gv = q.numpy(), kc.numpy(), vc.numpy()
+    tol = 2e-5 * np.abs(plain).max()
+    for r in (0, 1, 17, 64, 127):
+        wq, wk = kxo.rope(1, ql, kl, hs, plain[r, :ql].copy(), plain[r, ql:ql + kl].copy(), pos0 + r, s_tab, c_tab)
+        np.testing.assert_allclose(gq[r], wq, rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(gk[r], wk, rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(gv[r], plain[r, ql + kl:], rtol=1e-6, atol=tol)
+    assert not sp.numpy()[:4096].any()
+
+
 def test_swiglu_rows_fp16_result():
     rng = np.random.default_rng(3)
     T, half = 37, 1024
