@@ -467,6 +467,37 @@ def test_prompts_up_to_192_rows_stream_the_int8_weights(monkeypatch):
         x.close()
 
 
+def test_short_prompts_with_qkv_biases_and_interleaved_rope():
+    # the few-rows prompt pass with q / k / v biases (Qwen2's layout) ahead of the rotation, for both
+    # RoPE variants: against one fp32 decode step per row, K/V rows included
+    rng = np.random.default_rng(21)
+    for variant in (0, 1):
+        shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                     rope_variant=variant, rope_theta=1e6, rms_eps=1e-6)
+        m = host.Model(seq_len=256, group_size=GS, qkv_bias=True, **shape)
+        m.init_synthetic(77)
+        ref = host.Model(seq_len=256, group_size=GS, qkv_bias=True, **shape)
+        ref.init_synthetic(77)
+        for layer in range(2):
+            bq = (rng.standard_normal(512) * 0.3).astype(np.float32)
+            bk = (rng.standard_normal(128) * 0.3).astype(np.float32)
+            bv = (rng.standard_normal(128) * 0.3).astype(np.float32)
+            m.set_qkv_bias(layer, bq, bk, bv)
+            ref.set_qkv_bias(layer, bq, bk, bv)
+        for n in (9, 70, 150):
+            p = rng.integers(0, 1000, n).astype(np.int32)
+            got = m.prefill(p)
+            want = ref.prefill(p, exact=True)
+            assert np.abs(got - want).max() <= 4e-3 * np.abs(want).max(), (variant, n)
+            for layer in range(2):
+                k, v = m.read_kv(layer, n)
+                kr, vr = ref.read_kv(layer, n)
+                assert np.abs(k - kr).max() <= 4e-3 * np.abs(kr).max()
+                assert np.abs(v - vr).max() <= 4e-3 * np.abs(vr).max()
+        m.close()
+        ref.close()
+
+
 def test_short_prompts_use_the_kept_weight_images():
     # a model that keeps fp16 images of its weights runs prompts of 193..511 rows on the fp16 GEMMs
     # (with cut reductions: few tiles, many idle CUs) instead of the int8 single-pass kernel, whether
