@@ -805,6 +805,14 @@ def test_tensor_parallel_ranks_equal_single_rank(tp, shape):
     order = np.argsort(ref_last)
     if ref_last[order[-1]] - ref_last[order[-2]] > 1e-2 * np.abs(ref_last).max():
         assert outs[0][2][len(prompt)] == ref_hist[len(prompt)]
+    # short prompts under TP: the few-rows products on each rank's shard (where its widths allow)
+    for n in (9, 100):
+        short = rng.integers(0, 700, n).astype(np.int32)
+        ref_short = one.prefill(short)
+        outs = _run_ranks(ranks, lambda r, m: m.prefill(short))
+        for r in range(tp):
+            assert np.abs(outs[r] - ref_short).max() <= 2e-3 * np.abs(ref_short).max(), (n, r)
+            np.testing.assert_array_equal(outs[r], outs[0])
     with pytest.raises(kx.KxError):
         ranks[0].decode(1, use_graph=True)   # a host rendezvous cannot be captured
     for m in ranks:
