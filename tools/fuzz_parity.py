@@ -58,6 +58,23 @@ for _ in range(N):
     report("gemm_w8_rows", (T, K, M), np.abs(got - want), tol)
 assert not sp.numpy()[:4096].any(), "arrival tickets not back at zero"
 
+# ---- tiled prompt GEMMs: int8 single pass, two-pass, and the fp16-activation form (fp16 weight
+# images: one more rounding per weight, scales spread over three decades) ----
+for _ in range(N):
+    T = int(rng.integers(1, 600))
+    K = int(rng.integers(1, 10)) * 64
+    M = int(rng.integers(1, 12)) * 64
+    w, s = w8(K, M, 1e-5, 1e-2)
+    X = (rng.standard_normal((T, M)) * 10.0 ** rng.uniform(-1, 1)).astype(np.float16).astype(np.float32)
+    want = kxo.gemm_w8(X, w, s, GS, threads=8)
+    sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
+    base = np.abs(X.astype(np.float64)) @ sd.T
+    for name, got, ulps in (("gemm_w8", kx.gemm_w8(X, w, s, GS), 1.0),
+                            ("gemm_w8 two-pass", kx.gemm_w8(X, w, s, GS, two_pass=True), 2.0),
+                            ("gemm_w8_f16act", kx.gemm_w8_f16act(X.astype(np.float16), w, s, GS, split_ws=sp), 2.0)):
+        report(name, (T, K, M), np.abs(got - want), ulps * 2.0 ** -11 * base + 1e-7 * np.abs(want).max())
+assert not sp.numpy()[:4096].any(), "arrival tickets not back at zero"
+
 # ---- attention: prompt pass and decode step over the same cache ----
 for _ in range(N):
     hs = int(rng.choice([32, 64, 128]))
@@ -86,5 +103,5 @@ for _ in range(N):
     ref = kxo.mha(p_, H, 0, S, KVH * hs, H // KVH, hs, qd, kc, vc).reshape(H, hs)
     report("mha_decode", (H, KVH, hs, p_), np.abs(one - ref), 1e-4 * np.ones_like(ref))
 
-print(f"{3 * N + N} cases, {bad} mismatches")
+print(f"{7 * N} kernel runs checked, {bad} mismatches")
 sys.exit(1 if bad else 0)
