@@ -243,6 +243,11 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
     // ---- weights: one instruction = 8 rows x 128 bytes (the whole unit of those rows) ----
     // lane (r8, s) fetches piece s ^ key of its row, key = (row's index in its block of 16) >> 1
     unsigned woff[2][2], soff;
+    // A row holds M / 64 scales, a multiple of four (16 bytes) but not always of eight: the last
+    // four-unit block of a row may be half a block.  Its absent second half belongs to units that do
+    // not exist, so those lanes re-read the first half instead of reaching past the row -- for the
+    // matrix's last row that would be past the end of the scale array.
+    const unsigned srow = (unsigned)(a.M / 64) * 4u, shalf = (unsigned)(lane >> 5) * 16u;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
     {
       // lanes 0-31: the rows' first 16 bytes of a four-unit block of scales, lanes 32-63: the second
       const unsigned n = (unsigned)min(map.base + (lane & 15) * map.istep + ((lane >> 4) & 1) * map.rbstep, a.K - 1);
-      soff = n * (unsigned)(a.M / 64) * 4u + (unsigned)(lane >> 5) * 16u;
+      soff = n * (unsigned)(a.M / 64) * 4u;
     }
     const char* const wbase = reinterpret_cast<const char*>(a.w);
     const char* const sbase = reinterpret_cast<const char*>(a.scales);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
       const int U = u0 + u;
       if ((U & 3) == 0 || u == 0)
         __builtin_amdgcn_global_load_lds(
-            reinterpret_cast<const uint32_t*>(sbase + (soff + (unsigned)(U >> 2) * 32u)),
+            reinterpret_cast<const uint32_t*>(sbase + (soff + min((unsigned)(U >> 2) * 32u + shalf, srow - 16u))),
             (lds_ptr_t)(sring + ((U >> 2) % FR_SRING) * 1024), 16, 0, 0);
     };
     // fragment addresses: lane (j, q) = (lane & 15, lane >> 4)

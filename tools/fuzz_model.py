@@ -1,0 +1,70 @@
+"""Randomised model-level sweep (a tool, not a test): random small transformer shapes (head sizes
+32 / 64 / 128, grouped kv heads, both RoPE variants, with and without q/k/v biases, fp32 or 16-bit
+cache), synthetic weights.  For each: the fused graph-replayed token loop against the
+reference-structured loop (op::Layer objects, registry kernels), and batched prompt passes of random
+lengths against one fp32 decode step per row.
+Usage: fuzz_model.py [models] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
+import kx  # noqa: E402,F401
+from kx import host  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+bad = 0
+for i in range(N):
+    hs = int(rng.choice([32, 64, 128]))
+    KVH = int(rng.choice([1, 2, 4]))
+    H = KVH * int(rng.choice([1, 2, 4]))
+    dim = H * hs
+    if dim % 64 or (KVH * hs) % 64:   # the loader refuses widths that are not whole quant groups
+        continue
+    shape = dict(dim=dim, hidden_dim=int(rng.integers(2, 9)) * 128, layer_num=int(rng.integers(1, 4)), head_num=H,
+                 kv_head_num=KVH, vocab_size=int(rng.integers(50, 900)), rope_variant=int(rng.integers(0, 2)),
+                 rope_theta=float(rng.choice([1e4, 5e5, 1e6])), rms_eps=float(rng.choice([1e-5, 1e-6])))
+    bias = bool(rng.integers(0, 2))
+    kv16 = bool(rng.integers(0, 2))
+    seq = 640
+    case = dict(shape, bias=bias, kv16=kv16)
+    # the case goes out BEFORE it runs: after a device fault the last line printed names the culprit
+    print(f"model {i}: {case}", flush=True)
+    try:
+        m = host.Model(seq_len=seq, group_size=64, qkv_bias=bias, kv_f16=kv16, **shape)
+        ref = host.Model(seq_len=seq, group_size=64, qkv_bias=bias, **shape)
+        seed = int(rng.integers(1, 1 << 30))
+        m.init_synthetic(seed)
+        ref.init_synthetic(seed)
+        if bias:
+            for layer in range(shape["layer_num"]):
+                b = [(rng.standard_normal(n) * 0.2).astype(np.float32) for n in (dim, KVH * hs, KVH * hs)]
+                m.set_qkv_bias(layer, *b)
+                ref.set_qkv_bias(layer, *b)
+        toks = rng.integers(0, shape["vocab_size"], 8).astype(np.int32)
+        tol = 4e-3 if kv16 else 2e-4
+        for p, t in enumerate(toks):
+            a, b = m.step_logits(int(t), p), ref.forward_layers(int(t), p)
+            if not np.abs(a - b).max() <= tol * np.abs(b).max():
+                bad += 1
+                print(f"MISMATCH step {p}: {np.abs(a - b).max() / np.abs(b).max():.2e} {case}", flush=True)
+                break
+        for n in (int(rng.integers(2, 65)), int(rng.integers(65, 193)), int(rng.integers(193, 600))):
+            prompt = rng.integers(0, shape["vocab_size"], n).astype(np.int32)
+            got, want = m.prefill(prompt), ref.prefill(prompt, exact=True)
+            if not (np.isfinite(got).all() and np.abs(got - want).max() <= 6e-3 * np.abs(want).max()):
+                bad += 1
+                print(f"MISMATCH prefill {n} rows: {np.abs(got - want).max() / np.abs(want).max():.2e} {case}", flush=True)
+            m.decode(3, use_graph=True)
+            m.sync()
+            print(f"  prompt of {n} rows + 3 steps done", flush=True)
+        m.close()
+        ref.close()
+    except kx.KxError as e:
+        bad += 1
+        print(f"ERROR {e} {case}", flush=True)
+print(f"{N} models, {bad} problems")
+sys.exit(1 if bad else 0)
