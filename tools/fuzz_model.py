@@ -24,8 +24,8 @@ for i in range(N):
     dim = H * hs
     if dim % 64 or (KVH * hs) % 64:   # the loader refuses widths that are not whole quant groups
         continue
-    shape = dict(dim=dim, hidden_dim=int(rng.integers(2, 9)) * 128, layer_num=int(rng.integers(1, 4)), head_num=H,
-                 kv_head_num=KVH, vocab_size=int(rng.integers(50, 900)), rope_variant=int(rng.integers(0, 2)),
+    shape = dict(dim=dim, hidden_dim=int(rng.integers(1, 25)) * 64, layer_num=int(rng.integers(1, 4)), head_num=H,
+                 kv_head_num=KVH, vocab_size=int(rng.integers(2, 3000)), rope_variant=int(rng.integers(0, 2)),
                  rope_theta=float(rng.choice([1e4, 5e5, 1e6])), rms_eps=float(rng.choice([1e-5, 1e-6])))
     bias = bool(rng.integers(0, 2))
     kv16 = bool(rng.integers(0, 2))
