@@ -251,8 +251,11 @@ __device__ __forceinline__ void request_epilogue(const GemvW8Args& a, int r0, in
     if constexpr (MODE != GEMV_QKV_ROPE) {
       if (a.residual) res = a.residual[row];
     } else if ((r & 1) == 0) {
-      // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved)
-      const int in_head = row % a.head_size;
+      // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved).  Only q and k
+      // rows are rotated.  A v row keeps its own index inside the head (map_row leaves it alone), so
+      // twice that index can reach past the table row -- and past the table at the last position:
+      // such rows read entry 0, which nothing uses.
+      const int in_head = row < a.k1 ? row % a.head_size : 0;
       const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
       S.rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
       S.rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];

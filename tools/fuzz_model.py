@@ -6,6 +6,7 @@ lengths against one fp32 decode step per row.
 Usage: fuzz_model.py [models] [seed]"""
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -29,7 +30,7 @@ for i in range(N):
                  rope_theta=float(rng.choice([1e4, 5e5, 1e6])), rms_eps=float(rng.choice([1e-5, 1e-6])))
     bias = bool(rng.integers(0, 2))
     kv16 = bool(rng.integers(0, 2))
-    seq = 640
+    seq = int(rng.choice([256, 448, 640]))   # the last prompt and its three steps fill the cache to its end
     case = dict(shape, bias=bias, kv16=kv16)
     # the case goes out BEFORE it runs: after a device fault the last line printed names the culprit
     print(f"model {i}: {case}", flush=True)
@@ -52,7 +53,7 @@ for i in range(N):
                 bad += 1
                 print(f"MISMATCH step {p}: {np.abs(a - b).max() / np.abs(b).max():.2e} {case}", flush=True)
                 break
-        for n in (int(rng.integers(2, 65)), int(rng.integers(65, 193)), int(rng.integers(193, 600))):
+        for n in (int(rng.integers(2, 65)), int(rng.integers(65, 193)), int(rng.integers(193, seq - 3)), seq - 3):
             prompt = rng.integers(0, shape["vocab_size"], n).astype(np.int32)
             got, want = m.prefill(prompt), ref.prefill(prompt, exact=True)
             if not (np.isfinite(got).all() and np.abs(got - want).max() <= 6e-3 * np.abs(want).max()):
@@ -61,6 +62,40 @@ for i in range(N):
             m.decode(3, use_graph=True)
             m.sync()
             print(f"  prompt of {n} rows + 3 steps done", flush=True)
+        # the same model over two or four tensor-parallel ranks (objects of this process, reduces
+        # through a host rendezvous) where its widths divide
+        for tp in (2, 4):
+            if H % tp or KVH % tp or (shape["hidden_dim"] // tp) % 64 or shape["hidden_dim"] % tp or \
+                    (KVH // tp * hs) % 64 or bias or kv16:
+                continue
+            group = host.loopback_create(tp)
+            ranks = [host.Model(seq_len=seq, group_size=64, tp_size=tp, tp_rank=r, **shape) for r in range(tp)]
+            for r_ in ranks:
+                r_.init_synthetic(seed)
+                r_.join_loopback(group)
+            short = rng.integers(0, shape["vocab_size"], int(rng.integers(2, 193))).astype(np.int32)
+            want_tp = ref.prefill(short, exact=True)
+
+            def work(r, out):
+                out[r] = (np.stack([ranks[r].step_logits(int(t), p) for p, t in enumerate(toks[:4])]),
+                          ranks[r].prefill(short))
+            out = [None] * tp
+            ths = [threading.Thread(target=work, args=(r, out)) for r in range(tp)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join(120)
+            want_steps = np.stack([ref.forward_layers(int(t), p) for p, t in enumerate(toks[:4])])
+            for r in range(tp):
+                if out[r] is None or not (np.abs(out[r][0] - want_steps).max() <= 2e-4 * np.abs(want_steps).max()
+                                          and np.abs(out[r][1] - want_tp).max() <= 6e-3 * np.abs(want_tp).max()):
+                    bad += 1
+                    print(f"MISMATCH tp={tp} rank {r} {case}", flush=True)
+                    break
+            for r_ in ranks:
+                r_.close()
+            host.loopback_destroy(group)
+            print(f"  tp={tp} done", flush=True)
         m.close()
         ref.close()
     except kx.KxError as e:
