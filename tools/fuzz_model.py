@@ -3,6 +3,9 @@
 cache), synthetic weights.  For each: the fused graph-replayed token loop against the
 reference-structured loop (op::Layer objects, registry kernels), and batched prompt passes of random
 lengths against one fp32 decode step per row.
+Every case is printed BEFORE it runs: an out-of-bounds access faults the device and ends the process,
+and the last line printed then names the culprit (run it with its output on the terminal, one sweep
+per call, AMD_SERIALIZE_KERNEL=3 to have the failing launch named).
 Usage: fuzz_model.py [models] [seed]"""
 import os
 import sys
