@@ -405,6 +405,27 @@ int kx_embedding_dpos_f32(const int32_t* history_dev, const int32_t* pos_dev, co
  * caller-provided device int32 (the reference allocates per call). */
 int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index, void* stream);
 
+/* The three pieces the reference's CPU attention is assembled from (cpu/mha_kernel.cpp:19-60),
+ * behind ScaleKernel / SoftmaxInplaceKernel / ScaleSumKernel (kernels_interface.h:41-47,72-78; the
+ * reference registers CPU versions only).  Not on the hot path -- kx_mha_decode_f32 does all of it
+ * in one launch -- but a source written against those getters links and runs.
+ *   scale:     x[i] *= scale                                  (cpu/scale_kernel.cpp:3-8)
+ *   softmax:   x = exp(x - max x) / sum, in place, one vector  (cpu/softmax_kernel.cpp:4-15)
+ *   scale_sum: out[d] += sum_{i<=pos} scale[i] * value[i*stride + d], d < size
+ *                                                             (cpu/scale_sum_kernel.cpp:5-22) */
+int kx_scale_f32(float scale, float* x, int32_t n, void* stream);
+int kx_softmax_f32(float* x, int32_t n, void* stream);
+int kx_scale_sum_f32(const float* value, const float* scale, float* out, int32_t pos, int32_t size,
+                     int32_t stride, void* stream);
+/* quantize_q80 of the reference's exporter (tools/export_llama.py:49-73) on the device: for every
+ * group of group_size consecutive values scale = max|w| / 127 and q = round-half-even(w / scale),
+ * byte for byte what the exporter writes (an all-zero group: scale 0, zeros).  Used at load time to
+ * build the int8 classifier of a quant file whose classifier is tied to the fp32 embedding table --
+ * the exporter writes no int8 copy then (export_llama.py:183-192) and the reference points its
+ * int8 layer at the fp32 bytes (kuiper/source/model/llama3.cpp:273-286).  n % group_size == 0. */
+int kx_quantize_q80_f32(const float* w, size_t n, int32_t group_size, int8_t* q, float* scales,
+                        void* stream);
+
 /* End of one decode step, on the device (post_processing, llama3.cpp:801-813, without the
  * host round trip): token = argmax(logits); history[pos+1] = token (when history != NULL and in
  * range); pos += 1.  One launch: every workgroup reduces a slice to a {value, index} pair, and

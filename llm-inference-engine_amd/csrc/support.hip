@@ -387,6 +387,69 @@ __global__ __launch_bounds__(256) void step_end_candidates_kernel(const float* _
   step_embed(a, sm_tok);
 }
 
+// ---- the pieces the reference's CPU attention is assembled from (cpu/mha_kernel.cpp:19-60) ----
+// scale_inplace_cpu (cpu/scale_kernel.cpp:3-8): x *= scale.
+__global__ void scale_kernel(float scale, float* x, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= scale;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  __syncthreads();
+  return t;
+}
+
+// softmax_inplace_cpu (cpu/softmax_kernel.cpp:4-15): x = exp(x - max(x)) / sum; one workgroup.
+__global__ void softmax_kernel(float* x, int n) {
+  __shared__ float red[16];
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, x[i]);
+  mx = block_max(mx, red);
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float e = expf(x[i] - mx);
+    x[i] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, red);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = x[i] / sum;
+}
+
+// scale_sum_kernel_cpu (cpu/scale_sum_kernel.cpp:5-22): out[d] += sum_{i<=pos} scale[i] *
+// value[i*stride + d], d < size; the terms are added in order of i, one thread per d.
+__global__ void scale_sum_kernel(const float* __restrict__ value, const float* __restrict__ scale,
+                                 float* out, int pos, int size, int stride) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= size) return;
+  float acc = out[d];
+  for (int i = 0; i <= pos; ++i) acc = fmaf(scale[i], value[(size_t)i * stride + d], acc);
+  out[d] = acc;
+}
+
+// quantize_q80 (tools/export_llama.py:49-73): per group of `gs` consecutive values
+// scale = max|w| / 127, q = round_half_even(w / scale); one 64-lane wave per group.  IEEE division
+// and rintf, so the bytes equal the exporter's; an all-zero group gives scale 0 and zeros.
+__global__ void quantize_q80_kernel(const float* __restrict__ w, size_t groups, int gs,
+                                    int8_t* __restrict__ q, float* __restrict__ scales) {
+  const int lane = threadIdx.x & 63;
+  const size_t g = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const float* wg = w + g * (size_t)gs;
+  float wmax = 0.f;
+  for (int i = lane; i < gs; i += 64) wmax = fmaxf(wmax, fabsf(wg[i]));
+  wmax = wave_max(wmax);
+  const float scale = __fdiv_rn(wmax, 127.0f);
+  if (lane == 0) scales[g] = scale;
+  for (int i = lane; i < gs; i += 64)
+    q[g * (size_t)gs + i] = scale > 0.f ? (int8_t)rintf(__fdiv_rn(wg[i], scale)) : (int8_t)0;
+}
+
 // ---- seeded synthetic tensors, generated on the device ----
 // Element (i, j) of the GLOBAL matrix gets a value that depends only on (seed, i*ld + j), so a
 // tensor-parallel shard holds exactly the slice of the unsharded tensor.
@@ -637,6 +700,40 @@ extern "C" int kx_swiglu_rows_f16out(const float* in, int64_t ld_in, int32_t hal
   hipLaunchKernelGGL(swiglu_rows_kernel<_Float16>, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)),
                      dim3(256), 0, (hipStream_t)stream, in, ld_in, half, static_cast<_Float16*>(out16), ld_out,
                      rows);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_scale_f32(float scale, float* x, int32_t n, void* stream) {
+  if (!x || n <= 0) return KX_EINVAL;
+  hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scale, x, n);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_softmax_f32(float* x, int32_t n, void* stream) {
+  if (!x || n <= 0) return KX_EINVAL;
+  hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(n > 4096 ? 1024 : 256), 0, (hipStream_t)stream, x, n);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_scale_sum_f32(const float* value, const float* scale, float* out, int32_t pos,
+                                int32_t size, int32_t stride, void* stream) {
+  if (!value || !scale || !out || pos < 0 || size <= 0 || stride < size) return KX_EINVAL;
+  hipLaunchKernelGGL(scale_sum_kernel, dim3((size + 63) / 64), dim3(64), 0, (hipStream_t)stream, value,
+                     scale, out, pos, size, stride);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
+extern "C" int kx_quantize_q80_f32(const float* w, size_t n, int32_t group_size, int8_t* q,
+                                   float* scales, void* stream) {
+  if (!w || !q || !scales || group_size <= 0 || n == 0 || n % (size_t)group_size) return KX_EINVAL;
+  const size_t groups = n / (size_t)group_size;
+  if ((groups + 3) / 4 > 0x7fffffffull) return KX_EINVAL;
+  hipLaunchKernelGGL(quantize_q80_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, w, groups, group_size, q, scales);
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

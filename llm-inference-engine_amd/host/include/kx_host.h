@@ -94,6 +94,13 @@ int kxm_test_kv_layout(int32_t layers, int32_t seq_len, int32_t kv_head_num, int
                        int32_t layer_idx, int64_t* k_off, int64_t* v_off, int64_t* total_bytes);
 /* Registry contract: returns 1 when every getter hands back a kernel for kDeviceHIP. */
 int kxm_test_registry(void);
+/* One decode-attention call assembled from the registry's matmul / softmax / scale-sum kernels the
+ * way the reference's CPU mha_kernel assembles it (cpu/mha_kernel.cpp:10-60); out receives
+ * [head_num*head_size] results followed by the same values through the scale kernel (x 2). */
+int kxm_test_mha_from_registry_pieces(const float* q, const float* kcache, const float* vcache,
+                                      int32_t layers, int32_t seq_len, int32_t head_num,
+                                      int32_t kv_mul, int32_t head_size, int32_t layer_idx,
+                                      int32_t pos, float* out);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // extern "C" shim over model::LlamaModel and a few layer-level probes (host/include/kx_host.h).
 #include "kx_host.h"
 
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -282,6 +283,60 @@ int kxm_test_registry(void) {
   return get_add_kernel(kHip) && get_emb_kernel(kHip) && get_matmul_kernel(kHip) &&
          get_matmul_kernel_quant8(kHip) && get_mha_kernel(kHip) && get_rmsnorm_kernel(kHip) &&
          get_rmsnorm_dim_kernel(kHip) && get_rope_kernel(kHip) && get_swiglu_kernel(kHip) &&
-         get_flash_attention_kernel(kHip);
+         get_flash_attention_kernel(kHip) && get_scale_kernel(kHip) && get_softmax_kernel(kHip) &&
+         get_scale_sum_kernel(kHip);
+}
+
+int kxm_test_mha_from_registry_pieces(const float* q, const float* kc, const float* vc, int32_t layers,
+                                      int32_t seq_len, int32_t head_num, int32_t kv_mul,
+                                      int32_t head_size, int32_t layer_idx, int32_t pos, float* out_host) {
+  // The body of the reference's CPU attention (cpu/mha_kernel.cpp:10-60) with kDeviceHIP: one
+  // matmul-kernel call per key, the softmax kernel per head, the scale-sum kernel per head.
+  using namespace kernel;
+  auto cfg = std::make_shared<CudaConfig>();
+  if (int rc = cfg->create_streams()) return rc;
+  const base::DataType f32 = base::DataType::kDataTypeFp32;
+  const int32_t kv_dim = head_num / kv_mul * head_size;
+  tensor::Tensor key = dev_from_host(f32, {layers, seq_len, kv_dim}, kc);
+  tensor::Tensor val = dev_from_host(f32, {layers, seq_len, kv_dim}, vc);
+  tensor::Tensor query = dev_from_host(f32, {head_num * head_size}, q);
+  tensor::Tensor score = dev_from_host(f32, {head_num, seq_len}, nullptr);
+  tensor::Tensor out = dev_from_host(f32, {head_num * head_size}, nullptr);
+  auto view = [&](std::vector<int32_t> dims, const float* ptr) {
+    tensor::Tensor t(f32, std::move(dims), false, nullptr, const_cast<float*>(ptr));
+    t.set_device_type(kHip);
+    return t;
+  };
+  const size_t layer_offset = (size_t)layer_idx * seq_len * kv_dim;
+  const float scale = 1.f / std::sqrt(static_cast<float>(head_size));
+  for (int32_t h = 0; h < head_num; ++h) {
+    float* score_head = score.ptr<float>() + (size_t)h * seq_len;
+    tensor::Tensor query_mat = view({head_size}, query.ptr<float>() + (size_t)h * head_size);
+    for (int32_t t = 0; t <= pos; ++t) {
+      const size_t cache_offset = (size_t)t * kv_dim + (size_t)(h / kv_mul) * head_size;
+      tensor::Tensor key_mat = view({1, head_size}, key.ptr<float>() + layer_offset + cache_offset);
+      tensor::Tensor score_mat = view({1}, score_head + t);
+      get_matmul_kernel(kHip)(query_mat, key_mat, score_mat, scale, cfg.get());
+    }
+    tensor::Tensor score_head_tensor = view({pos + 1}, score_head);
+    get_softmax_kernel(kHip)(score_head_tensor, cfg->stream);
+    float* out_head = out.ptr<float>() + (size_t)h * head_size;
+    if (int rc = kx_memset(out_head, 0, sizeof(float) * head_size, cfg->stream)) return rc;
+    tensor::Tensor output_tensor = view({head_size}, out_head);
+    tensor::Tensor value_tensor =
+        view({head_size}, val.ptr<float>() + layer_offset + (size_t)(h / kv_mul) * head_size);
+    get_scale_sum_kernel(kHip)(value_tensor, score_head_tensor, output_tensor, pos, head_size, kv_dim,
+                               cfg->stream);
+  }
+  // the scale kernel, on a copy of the finished rows: out2 = 2 * out behind the first head_num*hs floats
+  kx_stream_sync(cfg->stream);
+  out.to_cpu();
+  std::memcpy(out_host, out.ptr<float>(), out.byte_size());
+  tensor::Tensor twice = dev_from_host(f32, {head_num * head_size}, out_host);
+  get_scale_kernel(kHip)(2.0f, twice, cfg->stream);
+  kx_stream_sync(cfg->stream);
+  twice.to_cpu();
+  std::memcpy(out_host + (size_t)head_num * head_size, twice.ptr<float>(), twice.byte_size());
+  return 0;
 }
 }  // extern "C"

@@ -350,9 +350,9 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
     int32_t gs = 0;
     std::memcpy(&gs, static_cast<const uint8_t*>(blob) + 28, 4);
     if (gs != c.group_size) return base::error::ModelParseError("group size mismatch");
-    // A tied classifier has no int8 copy in the file (tools/export_llama.py:183-188); the
-    // reference then reads fp32 bytes as int8 (llama3.cpp:276-279).  Refuse instead.
-    if (shared) return base::error::ModelParseError("quant file with tied classifier has no int8 classifier");
+    // A tied classifier has no int8 copy in the file (tools/export_llama.py:183-192); the
+    // reference then reads the fp32 embedding bytes as int8 (llama3.cpp:273-286).  Here the int8
+    // classifier is made at load, below, by the exporter's own rule from the fp32 table.
   }
   const size_t dim = c.dim, hid = c.hidden_dim, L = c.layer_num, V = c.vocab_size;
   const size_t kvd = c.kv_dim;
@@ -457,17 +457,28 @@ base::Status LlamaModel::load_blob(const void* blob, size_t bytes) {
     ST_RET(upload_kind(hid, dim, up_1));
     ST_RET(upload_kind(dim, hid, up_2));
     ST_RET(upload_kind(hid, dim, up_3));
-    cls_w = p;
-    cls_s = reinterpret_cast<const float*>(p + V * dim);
-    p += msize(V, dim);
+    if (!shared) {
+      cls_w = p;
+      cls_s = reinterpret_cast<const float*>(p + V * dim);
+      p += msize(V, dim);
+    }
     emb = reinterpret_cast<const float*>(p);        p += V * dim * 4;
     attn_norm = reinterpret_cast<const float*>(p);  p += L * dim * 4;
     ffn_norm = reinterpret_cast<const float*>(p);   p += L * dim * 4;
     final_norm = reinterpret_cast<const float*>(p); p += dim * 4;
   }
   if (p > end) return base::error::ModelParseError("blob truncated");
-  ST_RET(upload_matrix(cls_, 0, cls_w, cls_s, V, dim, c.vocab_row0, c.vocab_local, 0, dim));
   KX_RET(kx_memcpy_h2d(emb_, emb, V * dim * 4, nullptr));
+  if (quant_ && shared) {
+    // quantize_q80 (tools/export_llama.py:49-73) of the rank's rows of the embedding table, on the
+    // device: what the exporter writes for a classifier of its own.  Groups never straddle rows
+    // (dim is a multiple of the group size).
+    KX_RET(kx_quantize_q80_f32(emb_ + (size_t)c.vocab_row0 * dim, (size_t)c.vocab_local * dim, c.group_size,
+                               static_cast<int8_t*>(cls_.w), cls_.s, hip_->stream));
+    KX_RET(kx_stream_sync(hip_->stream));
+  } else {
+    ST_RET(upload_matrix(cls_, 0, cls_w, cls_s, V, dim, c.vocab_row0, c.vocab_local, 0, dim));
+  }
   for (size_t l = 0; l < L; ++l) {
     KX_RET(kx_memcpy_h2d(layers_[l].attn_norm, reinterpret_cast<const uint8_t*>(attn_norm) + l * dim * 4,
                          dim * 4, nullptr));
@@ -1064,6 +1075,13 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   const bool f16_ok = (gs & (gs - 1)) == 0 && gs >= 16 && dim % 64 == 0 && ql % 64 == 0 &&
                       hl % 64 == 0 && dim % gs == 0 && ql % gs == 0 && hl % gs == 0 &&
                       (c.head_size == 32 || c.head_size == 64 || c.head_size == 128);
+  // A/B switches (tools and tests), read once per call
+  const char* env_rows_max = getenv("KX_PREFILL_ROWS_MAX");
+  const bool env_no_rows = getenv("KX_PREFILL_NO_ROWS_KERNEL") != nullptr;
+  const bool env_unfused = getenv("KX_PREFILL_ROWS_UNFUSED") != nullptr;
+  const char* env_f16_min = getenv("KX_PREFILL_F16_MIN_ROWS");
+  // the fp16-output attention kernel the 16-bit forms end in exists for these head sizes only
+  const bool attn16_ok = c.head_size == 32 || c.head_size == 64 || c.head_size == 128;
   int32_t rows = 0;
   for (int32_t p0 = pos0; p0 < pos0 + n; p0 += rows) {
     rows = pos0 + n - p0 < chunk ? pos0 + n - p0 : chunk;
@@ -1080,18 +1098,16 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     // Up to 192 rows the int8 weights are streamed once against all rows (kx_gemm_w8_rows_f16act):
     // no fp16 image involved (Llama-3-8B, 16 / 32 / 64 / 96 / 128 / 192 rows: 3.2 / 3.6 / 4.6 / 5.6 /
     // 5.8 / 7.4 ms against 16.4 / 6.0 / 7.0 / 8.3 / 9.0 / 10.7 ms for the tiled kernels).
-    int32_t few_rows_max = 192;
-    if (const char* e = getenv("KX_PREFILL_ROWS_MAX")) few_rows_max = atoi(e);  // A/B runs
+    const int32_t few_rows_max = env_rows_max ? atoi(env_rows_max) : 192;
     const bool few_rows = rows <= few_rows_max && gs == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 &&
-                          !getenv("KX_PREFILL_NO_ROWS_KERNEL");  // the switch: A/B runs and tests
+                          attn16_ok && !env_no_rows;
     // SwiGLU, and bias + RoPE + K/V placement, ride in the few-rows products' launches where the shapes
-    // allow (whole 128-row tiles of q, k and v rows); KX_PREFILL_ROWS_UNFUSED: A/B runs and tests
-    const bool rows_fused = few_rows && !getenv("KX_PREFILL_ROWS_UNFUSED");
-    const bool rows_fused_rope = rows_fused && ql % 128 == 0 && kl % 128 == 0 &&
-                                 (c.head_size == 32 || c.head_size == 64 || c.head_size == 128);
+    // allow (whole 128-row tiles of q, k and v rows)
+    const bool rows_fused = few_rows && !env_unfused;
+    const bool rows_fused_rope = rows_fused && ql % 128 == 0 && kl % 128 == 0;
     if (!few_rows && f16_ok && rows >= 32) ST_RET(reserve_weight_images());
     int32_t f16_min_rows = weight_images_ == 1 ? 32 : 512;
-    if (const char* e = getenv("KX_PREFILL_F16_MIN_ROWS")) f16_min_rows = atoi(e);  // A/B runs
+    if (env_f16_min) f16_min_rows = atoi(env_f16_min);
     const bool f16_chunk = !few_rows && f16_ok && rows >= f16_min_rows;
     for (int32_t l = 0; l < c.layer_num; ++l) {
       LayerWeights& lw = layers_[l];

@@ -175,6 +175,31 @@ void swiglu_kernel_hip(const tensor::Tensor& input1, const tensor::Tensor& input
      "kx_swiglu_f32");
 }
 
+// The pieces of the reference's CPU attention (cpu/mha_kernel.cpp:38-59), each one launch here.
+void scale_inplace_hip(float scale, const tensor::Tensor& input, void* stream) {
+  CHECK(!input.is_empty());  // cpu/scale_kernel.cpp:5
+  ok(kx_scale_f32(scale, out_ptr<float>(input), static_cast<int32_t>(input.size()), stream),
+     "kx_scale_f32");
+}
+
+void softmax_inplace_hip(const tensor::Tensor& input, void* stream) {
+  CHECK(!input.is_empty());
+  ok(kx_softmax_f32(out_ptr<float>(input), static_cast<int32_t>(input.size()), stream),
+     "kx_softmax_f32");
+}
+
+void scale_sum_kernel_hip(const tensor::Tensor& value, const tensor::Tensor& scale,
+                          const tensor::Tensor& output, int pos, int size, int stride, void* stream) {
+  CHECK_EQ(value.is_empty(), false);  // cpu/scale_sum_kernel.cpp:9-13
+  CHECK_EQ(scale.is_empty(), false);
+  CHECK_EQ(output.is_empty(), false);
+  CHECK_EQ(static_cast<size_t>(size), value.size());
+  CHECK_EQ(static_cast<size_t>(size), output.size());
+  ok(kx_scale_sum_f32(value.ptr<float>(), scale.ptr<float>(), out_ptr<float>(output), pos, size, stride,
+                      stream),
+     "kx_scale_sum_f32");
+}
+
 void flash_attention_kernel_hip(const tensor::Tensor& query, const tensor::Tensor& key,
                                 const tensor::Tensor& value, const tensor::Tensor& output,
                                 int32_t head_num, int32_t kv_head_num, int32_t head_size,

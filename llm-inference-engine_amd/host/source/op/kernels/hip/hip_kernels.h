@@ -30,6 +30,10 @@ void rope_kernel_hip(int32_t dim, int32_t kv_dim, int32_t head_size, const tenso
                      const tensor::Tensor& sin_cache, const tensor::Tensor& cos_cache, void* stream);
 void swiglu_kernel_hip(const tensor::Tensor& input1, const tensor::Tensor& input2,
                        const tensor::Tensor& output, void* stream);
+void scale_inplace_hip(float scale, const tensor::Tensor& input, void* stream);
+void softmax_inplace_hip(const tensor::Tensor& input, void* stream);
+void scale_sum_kernel_hip(const tensor::Tensor& value, const tensor::Tensor& scale,
+                          const tensor::Tensor& output, int pos, int size, int stride, void* stream);
 void flash_attention_kernel_hip(const tensor::Tensor& query, const tensor::Tensor& key,
                                 const tensor::Tensor& value, const tensor::Tensor& output,
                                 int32_t head_num, int32_t kv_head_num, int32_t head_size,

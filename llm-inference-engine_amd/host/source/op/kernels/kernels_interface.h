@@ -45,6 +45,14 @@ typedef void (*RoPEKernel)(int32_t dim, int32_t kv_dim, int32_t head_size,
                            const tensor::Tensor& input_pos, const tensor::Tensor& sin_cache,
                            const tensor::Tensor& cos_cache, void* stream);
 
+typedef void (*ScaleKernel)(float scale, const tensor::Tensor& input, void* stream);
+
+typedef void (*SoftmaxInplaceKernel)(const tensor::Tensor& input, void* stream);
+
+typedef void (*ScaleSumKernel)(const tensor::Tensor& value, const tensor::Tensor& scale,
+                               const tensor::Tensor& output, int t, int size, int stride,
+                               void* stream);
+
 typedef void (*FlashAttentionKernel)(const tensor::Tensor& query, const tensor::Tensor& key,
                                      const tensor::Tensor& value, const tensor::Tensor& output,
                                      int32_t head_num, int32_t kv_head_num, int32_t head_size,
@@ -60,6 +68,9 @@ MHAKernel get_mha_kernel(base::DeviceType device_type);
 RMSNormKernel get_rmsnorm_kernel(base::DeviceType device_type);
 RMSNormKernelDim get_rmsnorm_dim_kernel(base::DeviceType device_type);
 RoPEKernel get_rope_kernel(base::DeviceType device_type);
+ScaleKernel get_scale_kernel(base::DeviceType device_type);
+SoftmaxInplaceKernel get_softmax_kernel(base::DeviceType device_type);
+ScaleSumKernel get_scale_sum_kernel(base::DeviceType device_type);
 SwigluKernel get_swiglu_kernel(base::DeviceType device_type, void* stream = nullptr);
 FlashAttentionKernel get_flash_attention_kernel(base::DeviceType device_type);
 

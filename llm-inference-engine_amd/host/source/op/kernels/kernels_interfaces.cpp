@@ -26,6 +26,9 @@ KX_GETTER(MHAKernel, get_mha_kernel, mha_kernel_hip, "an mha")
 KX_GETTER(RMSNormKernel, get_rmsnorm_kernel, rmsnorm_kernel_hip, "a rmsnorm")
 KX_GETTER(RMSNormKernelDim, get_rmsnorm_dim_kernel, rmsnorm_kernel_hip_dim, "a rmsnorm dim")
 KX_GETTER(RoPEKernel, get_rope_kernel, rope_kernel_hip, "a rope")
+KX_GETTER(ScaleKernel, get_scale_kernel, scale_inplace_hip, "a scale")
+KX_GETTER(SoftmaxInplaceKernel, get_softmax_kernel, softmax_inplace_hip, "a softmax")
+KX_GETTER(ScaleSumKernel, get_scale_sum_kernel, scale_sum_kernel_hip, "a scale and reduce")
 KX_GETTER(FlashAttentionKernel, get_flash_attention_kernel, flash_attention_kernel_hip,
           "a flash attention")
 #undef KX_GETTER

@@ -121,6 +121,10 @@ SIGNATURES = {
     "kx_embedding_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "kx_embedding_dpos_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "kx_argmax_f32": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "kx_scale_f32": (C.c_int, [_f, _vp, _i32, _vp]),
+    "kx_softmax_f32": (C.c_int, [_vp, _i32, _vp]),
+    "kx_scale_sum_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "kx_quantize_q80_f32": (C.c_int, [_vp, _sz, _i32, _vp, _vp, _vp]),
     "kx_step_workspace_bytes": (_sz, []),
     "kx_decode_step_end": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "kx_gemv_w8_fused_f32": (C.c_int, [_vp, _vp]),
@@ -463,3 +467,12 @@ def gemm_w8(X, w, s, group_size=64, two_pass=False):
         check(lib().kx_gemm_w8_f32(dx.ptr, dw.ptr, ds.ptr, group_size, dy.ptr, T, M, K, None),
               "kx_gemm_w8_f32")
     return dy.numpy(np.float32, (T, K))
+
+
+def quantize_q80(w, group_size=64):
+    """quantize_q80 on the device: (int8 values shaped like w, fp32 scales [w.size / group_size])."""
+    w = np.ascontiguousarray(w, np.float32)
+    dw = Buf.from_numpy(w)
+    dq, ds = Buf.zeros(w.size, np.int8), Buf.zeros(w.size // group_size)
+    check(lib().kx_quantize_q80_f32(dw.ptr, w.size, group_size, dq.ptr, ds.ptr, None), "kx_quantize_q80_f32")
+    return dq.numpy(np.int8, w.shape), ds.numpy(np.float32, (w.size // group_size,))

@@ -81,6 +81,7 @@ def hlib():
         L.kxm_test_mha_layer.argtypes = [_vp, _vp, _vp] + [_i32] * 7 + [_vp]
         L.kxm_test_mha_layer_no_workspace.argtypes = [_vp, _vp, _vp] + [_i32] * 7 + [_vp]
         L.kxm_test_flash_layer.argtypes = [_vp, _vp, _vp] + [_i32] * 8 + [_vp]
+        L.kxm_test_mha_from_registry_pieces.argtypes = [_vp, _vp, _vp] + [_i32] * 7 + [_vp]
         L.kxm_test_kv_layout.argtypes = [_i32] * 5 + [C.POINTER(C.c_int64)] * 3
         _hlib = L
     return _hlib
@@ -326,6 +327,19 @@ def mha_layer_no_workspace(q, kc, vc, head_num, kv_mul, head_size, layer_idx, po
                                                   _p(out)),
            "MultiHeadAttention::forward (no workspace)")
     return out.reshape(head_num, head_size)
+
+
+def mha_from_registry_pieces(q, kc, vc, head_num, kv_mul, head_size, layer_idx, pos):
+    """(attention rows, the same rows through the scale kernel with factor 2)."""
+    L, S, _ = kc.shape
+    out = np.empty(2 * head_num * head_size, np.float32)
+    hcheck(hlib().kxm_test_mha_from_registry_pieces(_p(np.ascontiguousarray(q, np.float32)),
+                                                    _p(np.ascontiguousarray(kc, np.float32)),
+                                                    _p(np.ascontiguousarray(vc, np.float32)), L, S,
+                                                    head_num, kv_mul, head_size, layer_idx, pos, _p(out)),
+           "attention from registry pieces")
+    a, b = out.reshape(2, head_num, head_size)
+    return a, b
 
 
 def flash_layer(q, kc, vc, head_num, kv_mul, head_size, layer_idx, pos):

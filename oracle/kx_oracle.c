@@ -42,7 +42,8 @@ void kxo_quantize_q80(const float* w, size_t n, int32_t group_size, int8_t* q, f
     float scale = wmax / 127.0f;
     scales[g] = scale;
     for (int32_t i = 0; i < group_size; ++i) {
-      float quant = wg[i] / scale;
+      /* an all-zero group: 0/0 in the exporter; the int8 it stores for that is 0 */
+      float quant = scale > 0.f ? wg[i] / scale : 0.f;
       /* torch.round: half to even == nearbyintf under the default rounding mode */
       q[g * (size_t)group_size + i] = (int8_t)nearbyintf(quant);
     }
@@ -444,9 +445,10 @@ int kxo_parse_legacy_q8(const void* blob, size_t bytes, kxo_weights* out) {
   if (read_header(h, c, &shared)) return -1;
   c->group_size = h[7]; /* model.cpp:74-80 */
   if (c->group_size <= 0) return -1;
-  /* A tied classifier has no int8 copy in the file (export_llama.py:183-188) and the reference
-   * then points the int8 layer at fp32 data (llama3.cpp:276-279); not representable here. */
-  if (shared) return -3;
+  /* A tied classifier has no int8 copy in the file (export_llama.py:183-192); the reference then
+   * points the int8 layer at the fp32 embedding bytes (llama3.cpp:273-286).  Here the classifier
+   * is what the exporter would have written for an untied copy of the table: quantize_q80 of the
+   * fp32 embedding, below. */
   size_t dim = c->dim, hid = c->hidden_dim, L = c->layer_num, V = c->vocab_size;
   size_t hs = dim / c->head_num, kvd = hs * c->kv_head_num, gs = c->group_size;
   const char* p = (const char*)blob + 32; /* model.cpp:113-114 */
@@ -477,15 +479,19 @@ int kxo_parse_legacy_q8(const void* blob, size_t bytes, kxo_weights* out) {
   out->w1_q = qdst[4]; out->w1_s = sdst[4];
   out->w2_q = qdst[5]; out->w2_s = sdst[5];
   out->w3_q = qdst[6]; out->w3_s = sdst[6];
+  int8_t* cq = NULL;
+  float* cs = NULL;
   {
     size_t n = V * dim;
     if (n % gs) return -4;
-    int8_t* cq = (int8_t*)malloc(n);
-    float* cs = (float*)malloc((n / gs) * sizeof(float));
-    if ((size_t)(p - (const char*)blob) + n + (n / gs) * 4 > bytes) return -2;
-    memcpy(cq, p, n);
-    memcpy(cs, p + n, (n / gs) * sizeof(float));
-    p += n + (n / gs) * sizeof(float);
+    cq = (int8_t*)malloc(n);
+    cs = (float*)malloc((n / gs) * sizeof(float));
+    if (!shared) {
+      if ((size_t)(p - (const char*)blob) + n + (n / gs) * 4 > bytes) return -2;
+      memcpy(cq, p, n);
+      memcpy(cs, p + n, (n / gs) * sizeof(float));
+      p += n + (n / gs) * sizeof(float);
+    }
     out->cls_q = cq; out->cls_s = cs;
   }
   /* fp32 tail: embedding, attention norms, ffn norms, final norm (export_llama.py:191-203;
@@ -498,5 +504,6 @@ int kxo_parse_legacy_q8(const void* blob, size_t bytes, kxo_weights* out) {
   out->attn_norm = t + V * dim;
   out->ffn_norm = out->attn_norm + L * dim;
   out->final_norm = out->ffn_norm + L * dim;
+  if (shared) kxo_quantize_q80(out->emb, V * dim, (int32_t)gs, cq, cs);
   return 0;
 }

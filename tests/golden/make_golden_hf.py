@@ -1,4 +1,4 @@
-"""Generates the half-split-RoPE fixtures g6 (Llama-3 family) and g7 (Qwen2 family).
+"""Generates the half-split-RoPE fixtures g6, g8 (Llama-3 family) and g7 (Qwen2 family).
 
 The reference's own route from a Hugging Face checkpoint to its on-disk layout is
 tools/export_llama3.py::load_hf_model (no q/k permutation, so the file keeps HF's half-split
@@ -17,6 +17,12 @@ values.  Run in the authoring container only; the reference never travels, only 
   g7_qwen2_fp32.bin  export_qwen2.legacy_export of a Qwen2ForCausalLM with non-zero q/k/v biases
                      (dim 128, 2 layers, 2 heads, 1 kv head, head 64, theta 1e6, eps 1e-6)
   g7_qwen2_fp32.npz  tokens, logits, greedy of the HF model
+  g8_llama3_tied_q8.bin  export_llama3.legacy_export_quant of a LlamaForCausalLM whose classifier is
+                     TIED to the embedding table (as Llama-3.2-1B's is): the exporter then writes
+                     no int8 classifier at all (export_llama.py:183-192) and a loader has to make one
+  g8_llama3_tied_q8.npz  tokens, logits, greedy of the HF model with every linear dequantised and the
+                     classifier = dequantised quantize_q80(embedding table), the table itself kept in
+                     fp32 for the lookups; plus that classifier's int8 values and scales (cls_q, cls_s)
   g7_qwen2_q8.bin    export_qwen2.legacy_export_quant of the same model (no biases in the file)
   g7_qwen2_q8.npz    logits/greedy of the HF model with dequantised weights, once with the biases
                      zeroed (what the file alone describes) and once with them kept
@@ -131,6 +137,46 @@ def g6():
              logits=logits, greedy=greedy)
 
 
+def g8():
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import export_llama3
+    torch.manual_seed(8)
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=2, vocab_size=192,
+                      rope_theta=5e5, max_position_embeddings=48, rms_norm_eps=1e-5,
+                      tie_word_embeddings=True, attention_bias=False, mlp_bias=False,
+                      attn_implementation="eager")
+    m = LlamaForCausalLM(cfg).eval().float()
+    assert m.lm_head.weight is m.model.embed_tokens.weight
+    g = torch.Generator().manual_seed(80)
+    with torch.no_grad():
+        # one table serves lookups and logits: a scale between the two the untied fixtures use
+        m.model.embed_tokens.weight.mul_(25.0)
+        for layer in m.model.layers:
+            layer.input_layernorm.weight.copy_(1.0 + 0.1 * torch.randn(128, generator=g))
+            layer.post_attention_layernorm.weight.copy_(1.0 + 0.1 * torch.randn(128, generator=g))
+            for name in ("q_proj", "k_proj", "v_proj"):
+                getattr(layer.self_attn, name).weight.mul_(3.0)
+        m.model.norm.weight.copy_(1.0 + 0.1 * torch.randn(128, generator=g))
+    out = os.path.join(HERE, "g8_llama3_tied_q8.bin")
+    with tempfile.TemporaryDirectory() as hf_dir:
+        m.save_pretrained(hf_dir)
+        _export(export_llama3, "legacy_export_quant", hf_dir, out)
+    with open(out, "rb") as f:
+        assert np.frombuffer(f.read(32), np.int32)[5] > 0, "the exporter should have flagged a shared classifier"
+    # the model the file describes: fp32 table for the lookups, an int8 classifier made from it
+    d = copy.deepcopy(m)
+    d.config.tie_word_embeddings = False
+    d.lm_head.weight = torch.nn.Parameter(d.model.embed_tokens.weight.detach().clone())
+    assert d.lm_head.weight is not d.model.embed_tokens.weight
+    cq, cs, _ = export_llama3.quantize_q80(d.lm_head.weight.detach(), GS)
+    d = _dequantised_copy(d, export_llama3.quantize_q80, zero_bias=False)
+    assert torch.equal(d.model.embed_tokens.weight, m.model.embed_tokens.weight)
+    tokens, [(logits, greedy, _)] = _pick_tokens([d], 45)
+    np.savez(os.path.join(HERE, "g8_llama3_tied_q8.npz"), tokens=tokens.numpy().astype(np.int32),
+             logits=logits, greedy=greedy, cls_q=cq.numpy().reshape(192, 128), cls_s=cs.numpy())
+
+
 def g7():
     from transformers import Qwen2Config, Qwen2ForCausalLM
     import export_qwen2
@@ -161,6 +207,7 @@ def g7():
 if __name__ == "__main__":
     g6()
     g7()
+    g8()
     for f in sorted(os.listdir(HERE)):
-        if f.startswith(("g6", "g7")):
+        if f.startswith(("g6", "g7", "g8")):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -181,6 +181,70 @@ def test_llama3_q8_hf_fixture_every_path(golden, golden_bytes):
     _prefill_decode_exact(make, g)
 
 
+LLAMA3_TIED_TINY = dict(dim=128, hidden_dim=320, layer_num=2, head_num=4, kv_head_num=2, vocab_size=192,
+                        rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+
+
+def test_llama3_q8_tied_classifier_fixture_every_path(golden, golden_bytes):
+    # the exporter writes no int8 classifier when it is tied to the embedding (Llama-3.2-1B is);
+    # load_blob quantises the fp32 table on the device with the exporter's rule: same bytes as the
+    # exporter computes, logits and greedy stream of the HF model on every path
+    g = golden("g8_llama3_tied_q8.npz")
+    blob = golden_bytes("g8_llama3_tied_q8.bin")
+    scale = np.abs(g["logits"]).max()
+
+    def make():
+        m = host.Model(seq_len=48, group_size=GS, **LLAMA3_TIED_TINY)
+        m.load_blob(blob)
+        return m
+    m = make()
+    np.testing.assert_array_equal(m.read_weight("cls"), g["cls_q"])
+    np.testing.assert_array_equal(m.read_weight("cls_s"), g["cls_s"])
+    m.close()
+    for path in ("forward_layers", "step_logits"):
+        m = make()
+        logits, greedy = _stream(getattr(m, path), g["tokens"], 16)
+        assert np.abs(logits - g["logits"]).max() <= 2e-5 * scale, path
+        assert greedy == g["greedy"].tolist(), path
+        m.close()
+    _prefill_decode_exact(make, g)
+    # over two tensor-parallel ranks each rank quantises its half of the table's rows
+    halves = []
+    for r in range(2):
+        m = host.Model(seq_len=48, group_size=GS, tp_size=2, tp_rank=r, **LLAMA3_TIED_TINY)
+        m.load_blob(blob)
+        halves.append((m.read_weight("cls"), m.read_weight("cls_s")))
+        m.close()
+    np.testing.assert_array_equal(np.concatenate([h[0] for h in halves]), g["cls_q"])
+    np.testing.assert_array_equal(np.concatenate([h[1] for h in halves]), g["cls_s"])
+
+
+def test_quantize_q80_on_the_device_equals_the_oracle():
+    rng = np.random.default_rng(80)
+    w = (rng.standard_normal((300, 192)) * 10.0 ** rng.uniform(-3, 2, (300, 1))).astype(np.float32)
+    w[7, :64] = 0                         # an all-zero group
+    w[9, 64:128] = np.arange(64) * 0.5    # exact halves: ties go to even
+    for gs in (64, 32, 128):
+        q, s = kx.quantize_q80(w, gs)
+        qo, so = kxo.quantize_q80(w, gs)
+        np.testing.assert_array_equal(s, so)
+        np.testing.assert_array_equal(q, qo)
+
+
+def test_attention_assembled_from_the_registry_pieces(golden):
+    # matmul-with-scale per key, softmax, scale-sum: the reference's CPU mha_kernel flow
+    # (cpu/mha_kernel.cpp:10-60) run with kDeviceHIP kernels, against the oracle's attention
+    rng = np.random.default_rng(12)
+    H, KVH, hs, S, pos, layer = 6, 2, 48, 40, 33, 1
+    kc = rng.standard_normal((2, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((2, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    got, twice = host.mha_from_registry_pieces(q, kc, vc, H, H // KVH, hs, layer, pos)
+    want = kxo.mha(pos, H, layer, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    assert np.abs(got - want).max() <= 2e-5
+    np.testing.assert_array_equal(twice, got * np.float32(2.0))
+
+
 def test_qwen2_fp32_hf_fixture_with_biases_layer_path(golden, golden_bytes):
     # fp32 file with q/k/v biases (qwen2.cpp:306-333) through op::MatmulLayer(has_bias) + registry
     g = golden("g7_qwen2_fp32.npz")

@@ -164,6 +164,42 @@ def test_llama3_q8_model_vs_hf(golden, golden_bytes):
     assert np.abs(lw - g["logits"]).max() > 1e-2 * np.abs(g["logits"]).max()
 
 
+def test_llama3_q8_tied_classifier_vs_hf(golden, golden_bytes):
+    # A quant file whose classifier is tied to the embedding table carries no int8 classifier
+    # (export_llama.py:183-192): the loader makes one from the fp32 table by the exporter's own
+    # quantize_q80.  Its bytes must equal what the exporter computes for that table, and the logits
+    # must be those of the HF model holding the dequantised classifier next to the fp32 table.
+    g = golden("g8_llama3_tied_q8.npz")
+    blob = golden_bytes("g8_llama3_tied_q8.bin")
+    assert np.frombuffer(blob[:32], np.int32)[5] == 192      # positive: shared classifier
+    cfg = kxo.Config(rope_variant=kxo.ROPE_HALF_SPLIT, rope_theta=5e5, rms_eps=1e-5)
+    m = kxo.Model(cfg, blob=blob, quant=True)
+    c = m.cfg
+    assert (c.dim, c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size, c.seq_len,
+            c.group_size) == (128, 320, 2, 4, 2, 192, 48, 64)
+    import ctypes as C
+    cq = np.ctypeslib.as_array(C.cast(m.w.cls_q, C.POINTER(C.c_int8)), shape=(192, 128))
+    cs = np.ctypeslib.as_array(C.cast(m.w.cls_s, C.POINTER(C.c_float)), shape=(192 * 128 // 64,))
+    np.testing.assert_array_equal(cq, g["cls_q"])
+    np.testing.assert_array_equal(cs, g["cls_s"])
+    logits, greedy = _run_stream(m, g["tokens"], 16)
+    assert np.abs(logits - g["logits"]).max() <= 2e-5 * np.abs(g["logits"]).max()
+    assert greedy.tolist() == g["greedy"].tolist()
+
+
+def test_quantize_q80_zero_group_and_ties():
+    # an all-zero group stays zeros with scale 0 (no NaN bytes); halves round to even
+    w = np.zeros(128, np.float32)
+    w[64:] = np.linspace(-127, 127, 64)
+    w[64 + 5] = 0.5 * 127 / 127          # quant value 0.5 -> 0
+    w[64 + 6] = 1.5                      # 1.5 -> 2
+    w[64 + 7] = 2.5                      # 2.5 -> 2
+    q, s = kxo.quantize_q80(w, 64)
+    assert s[0] == 0 and not q[:64].any()
+    assert s[1] == np.float32(127.0) / np.float32(127.0)
+    assert (q[64 + 5], q[64 + 6], q[64 + 7]) == (0, 2, 2)
+
+
 def test_qwen2_fp32_model_with_bias_vs_hf(golden, golden_bytes):
     g = golden("g7_qwen2_fp32.npz")
     m = kxo.Model(_qwen2_cfg(), blob=golden_bytes("g7_qwen2_fp32.bin"), quant=False, qkv_bias=True)

@@ -13,95 +13,101 @@ sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
 import kx  # noqa: E402
 from oracle import kxo  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-GS = 64
-bad = 0
+def run(N=40, seed=1):
+    """N cases per kernel from the generator seeded with `seed`; returns the number of mismatches."""
+    rng = np.random.default_rng(seed)
+    GS = 64
+    bad = 0
 
 
-def w8(K, M, scale_lo=1e-4, scale_hi=2e-2):
-    w = rng.integers(-127, 128, (K, M), dtype=np.int8)
-    s = rng.uniform(scale_lo, scale_hi, K * M // GS).astype(np.float32)
-    return w, s
+    def w8(K, M, scale_lo=1e-4, scale_hi=2e-2):
+        w = rng.integers(-127, 128, (K, M), dtype=np.int8)
+        s = rng.uniform(scale_lo, scale_hi, K * M // GS).astype(np.float32)
+        return w, s
 
 
-def report(name, case, err, tol):
-    global bad
-    if not np.all(err <= tol):
-        bad += 1
-        print(f"MISMATCH {name} {case}: worst {float((err - tol).max()):.3e} over the bound", flush=True)
-
-
-# ---- decode GEMV: any K, M a multiple of 64 ----
-for _ in range(N):
-    K = int(rng.integers(1, 700))
-    M = int(rng.integers(1, 40)) * 64
-    w, s = w8(K, M)
-    x = (rng.standard_normal(M) * 10.0 ** rng.uniform(-2, 2)).astype(np.float32)
-    got = kx.gemv_w8(x, w, s, GS)
-    want = kxo.gemv_w8(x, w, s, GS)
-    absum = np.abs(x.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w)).T
-    report("gemv_w8", (K, M), np.abs(got - want), 1e-5 * absum + 1e-30)
-
-# ---- few-rows product: T <= 192, M a multiple of 256 ----
-sp = kx.Buf.zeros(kx.lib().kx_gemm_split_workspace_bytes(), np.uint8)
-for _ in range(N):
-    T = int(rng.integers(2, 193))
-    K = int(rng.integers(1, 900))
-    M = int(rng.integers(1, 9)) * 256
-    w, s = w8(K, M)
-    X = (rng.standard_normal((T, M)) * 10.0 ** rng.uniform(-1, 1)).astype(np.float16).astype(np.float32)
-    got = kx.gemm_w8_rows(X, w, s, GS, split_ws=sp, half=True)
-    want = kxo.gemm_w8(X, w, s, GS, threads=8)
-    sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
-    tol = 2.0 ** -11 * (np.abs(X.astype(np.float64)) @ sd.T) + 1e-7 * np.abs(want).max()
-    report("gemm_w8_rows", (T, K, M), np.abs(got - want), tol)
-assert not sp.numpy()[:4096].any(), "arrival tickets not back at zero"
-
-# ---- tiled prompt GEMMs: int8 single pass, two-pass, and the fp16-activation form (fp16 weight
-# images: one more rounding per weight, scales spread over three decades) ----
-for _ in range(N):
-    T = int(rng.integers(1, 600))
-    K = int(rng.integers(1, 10)) * 64
-    M = int(rng.integers(1, 12)) * 64
-    w, s = w8(K, M, 1e-5, 1e-2)
-    X = (rng.standard_normal((T, M)) * 10.0 ** rng.uniform(-1, 1)).astype(np.float16).astype(np.float32)
-    want = kxo.gemm_w8(X, w, s, GS, threads=8)
-    sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
-    base = np.abs(X.astype(np.float64)) @ sd.T
-    for name, got, ulps in (("gemm_w8", kx.gemm_w8(X, w, s, GS), 1.0),
-                            ("gemm_w8 two-pass", kx.gemm_w8(X, w, s, GS, two_pass=True), 2.0),
-                            ("gemm_w8_f16act", kx.gemm_w8_f16act(X.astype(np.float16), w, s, GS, split_ws=sp), 2.0)):
-        report(name, (T, K, M), np.abs(got - want), ulps * 2.0 ** -11 * base + 1e-7 * np.abs(want).max())
-assert not sp.numpy()[:4096].any(), "arrival tickets not back at zero"
-
-# ---- attention: prompt pass and decode step over the same cache ----
-for _ in range(N):
-    hs = int(rng.choice([32, 64, 128]))
-    KVH = int(rng.choice([1, 2, 4]))
-    H = KVH * int(rng.choice([1, 2, 4, 7]))
-    Tq = int(rng.integers(1, 400))
-    pos = Tq - 1 + int(rng.integers(0, 100))
-    S = pos + 1 + int(rng.integers(0, 50))
-    spread = 10.0 ** rng.uniform(-0.5, 0.7)          # flat to sharply peaked score rows
-    kc = (rng.standard_normal((1, S, KVH * hs)) * spread).astype(np.float32)
-    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
-    q = (rng.standard_normal((Tq, H, hs)) * spread).astype(np.float32)
-    want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, 0, threads=8)
-    for f16_copies in (True, False):
-        got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0, f16_copies=f16_copies)
-        case = (H, KVH, hs, Tq, pos, round(float(spread), 2), f16_copies)
-        if not np.isfinite(got).all():
+    def report(name, case, err, tol):
+        nonlocal bad
+        if not np.all(err <= tol):
             bad += 1
-            print(f"NON-FINITE flash_attention {case}", flush=True)
-            continue
-        # fp16 rounding of q, k shifts a score by up to 2^-10 |q||k|: the bound follows the spread
-        report("flash_attention", case, np.abs(got - want), 3e-3 * max(1.0, spread * spread) * np.ones_like(want))
-    p_ = int(rng.integers(0, pos + 1))
-    qd = q[min(p_, Tq - 1)].reshape(-1)
-    one = kx.mha_decode(qd, kc, vc, p_, H, H // KVH, hs, 0)
-    ref = kxo.mha(p_, H, 0, S, KVH * hs, H // KVH, hs, qd, kc, vc).reshape(H, hs)
-    report("mha_decode", (H, KVH, hs, p_), np.abs(one - ref), 1e-4 * np.ones_like(ref))
+            print(f"MISMATCH {name} {case}: worst {float((err - tol).max()):.3e} over the bound", flush=True)
 
-print(f"{7 * N} kernel runs checked, {bad} mismatches")
-sys.exit(1 if bad else 0)
+
+    # ---- decode GEMV: any K, M a multiple of 64 ----
+    for _ in range(N):
+        K = int(rng.integers(1, 700))
+        M = int(rng.integers(1, 40)) * 64
+        w, s = w8(K, M)
+        x = (rng.standard_normal(M) * 10.0 ** rng.uniform(-2, 2)).astype(np.float32)
+        got = kx.gemv_w8(x, w, s, GS)
+        want = kxo.gemv_w8(x, w, s, GS)
+        absum = np.abs(x.astype(np.float64)) @ (np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w)).T
+        report("gemv_w8", (K, M), np.abs(got - want), 1e-5 * absum + 1e-30)
+
+    # ---- few-rows product: T <= 192, M a multiple of 256 ----
+    sp = kx.Buf.zeros(kx.lib().kx_gemm_split_workspace_bytes(), np.uint8)
+    for _ in range(N):
+        T = int(rng.integers(2, 193))
+        K = int(rng.integers(1, 900))
+        M = int(rng.integers(1, 9)) * 256
+        w, s = w8(K, M)
+        X = (rng.standard_normal((T, M)) * 10.0 ** rng.uniform(-1, 1)).astype(np.float16).astype(np.float32)
+        got = kx.gemm_w8_rows(X, w, s, GS, split_ws=sp, half=True)
+        want = kxo.gemm_w8(X, w, s, GS, threads=8)
+        sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
+        tol = 2.0 ** -11 * (np.abs(X.astype(np.float64)) @ sd.T) + 1e-7 * np.abs(want).max()
+        report("gemm_w8_rows", (T, K, M), np.abs(got - want), tol)
+    assert not sp.numpy()[:4096].any(), "arrival tickets not back at zero"
+
+    # ---- tiled prompt GEMMs: int8 single pass, two-pass, and the fp16-activation form (fp16 weight
+    # images: one more rounding per weight, scales spread over three decades) ----
+    for _ in range(N):
+        T = int(rng.integers(1, 600))
+        K = int(rng.integers(1, 10)) * 64
+        M = int(rng.integers(1, 12)) * 64
+        w, s = w8(K, M, 1e-5, 1e-2)
+        X = (rng.standard_normal((T, M)) * 10.0 ** rng.uniform(-1, 1)).astype(np.float16).astype(np.float32)
+        want = kxo.gemm_w8(X, w, s, GS, threads=8)
+        sd = np.repeat(s.astype(np.float64), GS).reshape(K, M) * np.abs(w.astype(np.float64))
+        base = np.abs(X.astype(np.float64)) @ sd.T
+        for name, got, ulps in (("gemm_w8", kx.gemm_w8(X, w, s, GS), 1.0),
+                                ("gemm_w8 two-pass", kx.gemm_w8(X, w, s, GS, two_pass=True), 2.0),
+                                ("gemm_w8_f16act", kx.gemm_w8_f16act(X.astype(np.float16), w, s, GS, split_ws=sp), 2.0)):
+            report(name, (T, K, M), np.abs(got - want), ulps * 2.0 ** -11 * base + 1e-7 * np.abs(want).max())
+    assert not sp.numpy()[:4096].any(), "arrival tickets not back at zero"
+
+    # ---- attention: prompt pass and decode step over the same cache ----
+    for _ in range(N):
+        hs = int(rng.choice([32, 64, 128]))
+        KVH = int(rng.choice([1, 2, 4]))
+        H = KVH * int(rng.choice([1, 2, 4, 7]))
+        Tq = int(rng.integers(1, 400))
+        pos = Tq - 1 + int(rng.integers(0, 100))
+        S = pos + 1 + int(rng.integers(0, 50))
+        spread = 10.0 ** rng.uniform(-0.5, 0.7)          # flat to sharply peaked score rows
+        kc = (rng.standard_normal((1, S, KVH * hs)) * spread).astype(np.float32)
+        vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+        q = (rng.standard_normal((Tq, H, hs)) * spread).astype(np.float32)
+        want = kxo.flash_attention(q, kc, vc, H, KVH, hs, S, pos, 0, threads=8)
+        for f16_copies in (True, False):
+            got = kx.flash_attention(q, kc, vc, H, KVH, hs, pos, 0, f16_copies=f16_copies)
+            case = (H, KVH, hs, Tq, pos, round(float(spread), 2), f16_copies)
+            if not np.isfinite(got).all():
+                bad += 1
+                print(f"NON-FINITE flash_attention {case}", flush=True)
+                continue
+            # fp16 rounding of q, k shifts a score by up to 2^-10 |q||k|: the bound follows the spread
+            report("flash_attention", case, np.abs(got - want), 3e-3 * max(1.0, spread * spread) * np.ones_like(want))
+        p_ = int(rng.integers(0, pos + 1))
+        qd = q[min(p_, Tq - 1)].reshape(-1)
+        one = kx.mha_decode(qd, kc, vc, p_, H, H // KVH, hs, 0)
+        ref = kxo.mha(p_, H, 0, S, KVH * hs, H // KVH, hs, qd, kc, vc).reshape(H, hs)
+        report("mha_decode", (H, KVH, hs, p_), np.abs(one - ref), 1e-4 * np.ones_like(ref))
+
+    print(f"{7 * N} kernel runs checked, {bad} mismatches", flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40,
+                      int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
