@@ -141,7 +141,7 @@ def g8():
     from transformers import LlamaConfig, LlamaForCausalLM
     import export_llama3
     torch.manual_seed(8)
-    cfg = LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=2,
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=384, num_hidden_layers=2,
                       num_attention_heads=4, num_key_value_heads=2, vocab_size=192,
                       rope_theta=5e5, max_position_embeddings=48, rms_norm_eps=1e-5,
                       tie_word_embeddings=True, attention_bias=False, mlp_bias=False,

@@ -91,7 +91,11 @@ def test_prompt_pass_with_a_head_size_the_fp16_attention_has_no_form_for():
         ref.init_synthetic(5)
         for n in (4, 16, 100, 192, 230):
             p = rng.integers(0, 777, n).astype(np.int32)
-            got, want = m.prefill(p), ref.prefill(p, exact=True)
+            got = m.prefill(p)
+            # the fused token loop has no attention form for these head sizes either: the
+            # reference-structured layer loop, one row at a time, is the comparison
+            for pos, t in enumerate(p):
+                want = ref.forward_layers(int(t), pos)
             assert np.isfinite(got).all()
             assert np.abs(got - want).max() <= 6e-3 * np.abs(want).max(), (hs, n)
         m.close()
@@ -100,10 +104,10 @@ def test_prompt_pass_with_a_head_size_the_fp16_attention_has_no_form_for():
 
 def test_randomised_kernel_sweep_fixed_seed():
     import fuzz_parity
-    assert fuzz_parity.run(6, 20261) == 0
+    assert fuzz_parity.run(40, 20261) == 0
 
 
 def test_randomised_model_sweep_fixed_seed(capfd):
     import fuzz_model
-    assert fuzz_model.run(4, 42) == 0
-    assert fuzz_model.run(3, 20262, head_sizes=(64, 128)) == 0
+    assert fuzz_model.run(60, 42)     # the sweep that found the rotary-table read == 0
+    assert fuzz_model.run(20, 20262, head_sizes=(64, 128)) == 0

@@ -181,7 +181,7 @@ def test_llama3_q8_hf_fixture_every_path(golden, golden_bytes):
     _prefill_decode_exact(make, g)
 
 
-LLAMA3_TIED_TINY = dict(dim=128, hidden_dim=320, layer_num=2, head_num=4, kv_head_num=2, vocab_size=192,
+LLAMA3_TIED_TINY = dict(dim=128, hidden_dim=384, layer_num=2, head_num=4, kv_head_num=2, vocab_size=192,
                         rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
 
 

@@ -176,7 +176,7 @@ def test_llama3_q8_tied_classifier_vs_hf(golden, golden_bytes):
     m = kxo.Model(cfg, blob=blob, quant=True)
     c = m.cfg
     assert (c.dim, c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size, c.seq_len,
-            c.group_size) == (128, 320, 2, 4, 2, 192, 48, 64)
+            c.group_size) == (128, 384, 2, 4, 2, 192, 48, 64)
     import ctypes as C
     cq = np.ctypeslib.as_array(C.cast(m.w.cls_q, C.POINTER(C.c_int8)), shape=(192, 128))
     cs = np.ctypeslib.as_array(C.cast(m.w.cls_s, C.POINTER(C.c_float)), shape=(192 * 128 // 64,))
