@@ -70,6 +70,24 @@ int kx_graph_end_capture(void* stream, void** graph_exec);
 int kx_graph_launch(void* graph_exec, void* stream);
 int kx_graph_destroy(void* graph_exec);
 
+/* ---------------- bounds-checking build (make BOUNDS=1; no reference counterpart) ----------------
+ * A library built with -DKX_BOUNDS compares the address of every global load, store and LDS-DMA
+ * transfer of its kernels with the kx_malloc block its operand points into.  A violation does not
+ * trap: the access is redirected to the block's first byte and recorded.  kx_bounds_report copies
+ * up to max_records records (and the total number of violations, which may be larger than what the
+ * record holds) to the host after a device synchronise; kx_bounds_reset clears the record.  In a
+ * normal build kx_bounds_enabled() is 0 and the other two return KX_EUNSUPPORTED.
+ * file_id: 1 gemv_w8, 2 gemm_w8_rows, 3 gemm_w8, 4 gemm_f16, 5 attn_decode, 6 attn_prefill,
+ * 7 support, 8 gemv_f32; operand: the index the kernel file gives the buffer; offset: byte offset
+ * of the access from the block's start; extent: the block's size in bytes. */
+typedef struct kx_bounds_record {
+  int32_t file_id, line, operand, pad_;
+  int64_t offset, extent;
+} kx_bounds_record;
+int kx_bounds_enabled(void);
+int kx_bounds_report(kx_bounds_record* out, int32_t max_records, uint64_t* total);
+int kx_bounds_reset(void);
+
 /* ---------------- W8A32 group-quant GEMV (decode) ----------------
  * Replaces matmul_kernel_cu_qint8 / matmul_kernel_cu_fp32int8
  * (kuiper/source/op/kernels/cuda/matmul_kernel.cu:56-87,111-134), reached through

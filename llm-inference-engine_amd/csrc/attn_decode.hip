@@ -19,9 +19,13 @@
 #include <cstdlib>
 #include <mutex>
 
+#define KX_FILE_ID 5
 #include "kx_common.hpp"
 
 namespace kx {
+
+// operands of the bounds-checking build
+enum AttnOperand { AB_Q, AB_K, AB_V, AB_OUT, AB_WS, AB_TICKETS, AB_POS };
 
 constexpr int kAttnWaves = 4;
 constexpr int kMaxSplits = 128;
@@ -104,13 +108,13 @@ __device__ __forceinline__ f32x4 load_kv4(const _Float16* p) {
 template <int HS, typename KVT>
 __device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __restrict__ kbase,
                                                const KVT* __restrict__ vbase, int key0, int last,
-                                               int kv_dim, int n, int g) {
+                                               int kv_dim, int n, int g KX_BPARAM(7)) {
   constexpr int NJ = AttnTile<HS>::NJ, NH = AttnTile<HS>::NH;
   constexpr int DLV = HS >= 64 ? 16 : HS / 4;  // dim-lanes that carry data
   // K: lane (key n, g) loads K[key][16j+4g .. +4)
   const KVT* kr = kbase + (size_t)min(key0 + n, last) * kv_dim + 4 * g;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) T.k[j] = load_kv4(kr + 16 * j);
+  for (int j = 0; j < NJ; ++j) T.k[j] = load_kv4(KX_CKPN(AB_K, kr + 16 * j, 4 * sizeof(KVT)));
   // V: lane (dim-lane n, g) loads V[key0+4g+r][64h+4n .. +4)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -118,7 +122,7 @@ __device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __res
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       T.v[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (n < DLV) T.v[r][h] = load_kv4(vr + 64 * h);
+      if (n < DLV) T.v[r][h] = load_kv4(KX_CKPN(AB_V, vr + 64 * h, 4 * sizeof(KVT)));
     }
   }
 }
@@ -141,14 +145,14 @@ struct AttnTile4 {
 template <typename KVT>
 __device__ __forceinline__ void attn_load_tile4(AttnTile4& T, const KVT* __restrict__ kbase,
                                                 const KVT* __restrict__ vbase, int key0, int last,
-                                                int kv_dim, int lane) {
+                                                int kv_dim, int lane KX_BPARAM(7)) {
   const KVT* kr = kbase + (size_t)min(key0 + (lane & 15), last) * kv_dim + 4 * (lane >> 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) T.k[j] = load_kv4(kr + 16 * j);
+  for (int j = 0; j < 8; ++j) T.k[j] = load_kv4(KX_CKPN(AB_K, kr + 16 * j, 4 * sizeof(KVT)));
   const int hi = lane >> 5, c4 = (lane & 31) * 4;
 #pragma unroll
   for (int st = 0; st < 8; ++st)
-    T.v[st] = load_kv4(vbase + (size_t)min(key0 + 2 * st + hi, last) * kv_dim + c4);
+    T.v[st] = load_kv4(KX_CKPN(AB_V, vbase + (size_t)min(key0 + 2 * st + hi, last) * kv_dim + c4, 4 * sizeof(KVT)));
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
     const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale,
-    unsigned long long* __restrict__ trace) {
+    unsigned long long* __restrict__ trace KX_BPARAM(7)) {
   // optional timeline (tools/bench_attn.py with KX_ATTN_TRACE): wall-clock stamps (100 MHz), 8 per
   // workgroup
   auto stamp = [&](int slot) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   const int kvh = blockIdx.x, split = blockIdx.y;
   // The position may live in device memory so a captured launch can be replayed as it advances;
   // the grid is then sized for the longest context and surplus splits leave at once.
-  const int last = pos_dev ? *pos_dev : last_val;
+  const int last = pos_dev ? *KX_CKP(AB_POS, pos_dev) : last_val;
   const int ntiles = (last >> 4) + 1;
   const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x, sizeof(KVT) == 4);
   const int nsplit = cut.nsplit;
@@ -202,11 +206,11 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     f32x4 qf4[8];
     const float* qrow = q + ((size_t)kvh * kv_mul + min(hd, kv_mul - 1)) * HS + 4 * qd;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf4[j] = *reinterpret_cast<const f32x4*>(qrow + 16 * j);
+    for (int j = 0; j < 8; ++j) qf4[j] = *KX_CKP(AB_Q, reinterpret_cast<const f32x4*>(qrow + 16 * j));
 
     int t = t_begin + wave;
     AttnTile4 cur;
-    if (t < t_end) attn_load_tile4<KVT>(cur, kbase, vbase, t << 4, last, kv_dim, lane);
+    if (t < t_end) attn_load_tile4<KVT>(cur, kbase, vbase, t << 4, last, kv_dim, lane KX_BFWD);
     // single-tile form: without the fences the scheduler sinks the tile loads into the product
     // loop and waits for them one at a time (the prefetching form schedules better without)
     if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       AttnTile4 nxt;
       const bool more = t + kAttnWaves < t_end;
       if (PREFETCH && more)
-        attn_load_tile4<KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane);
+        attn_load_tile4<KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
       // ---- scores: rows = keys 4kb..4kb+3, columns = heads, this lane's quarter of the dims ----
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       }
       if (more) {
         if (PREFETCH) cur = nxt;
-        else attn_load_tile4<KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane);
+        else attn_load_tile4<KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
       }
       if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
     }
@@ -310,13 +314,13 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   const float* qrow = q + ((size_t)kvh * kv_mul + min(n, kv_mul - 1)) * HS + 4 * g;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + 16 * j);
+    const f32x4 v = *KX_CKP(AB_Q, reinterpret_cast<const f32x4*>(qrow + 16 * j));
     qf[j][0] = v.x; qf[j][1] = v.y; qf[j][2] = v.z; qf[j][3] = v.w;
   }
 
   int t = t_begin + wave;
   AttnTile<HS> cur;
-  if (t < t_end) attn_load_tile<HS, KVT>(cur, kbase, vbase, t << 4, last, kv_dim, n, g);
+  if (t < t_end) attn_load_tile<HS, KVT>(cur, kbase, vbase, t << 4, last, kv_dim, n, g KX_BFWD);
 
   f32x4 o[NH][4];
 #pragma unroll
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     AttnTile<HS> nxt;
     const bool more = t + kAttnWaves < t_end;
     if (PREFETCH && more)
-      attn_load_tile<HS, KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
+      attn_load_tile<HS, KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g KX_BFWD);
     // ---- S^T[key][head] = K . Q^T (two independent accumulation chains) ----
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       }
     if (more) {
       if (PREFETCH) cur = nxt;
-      else attn_load_tile<HS, KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g);
+      else attn_load_tile<HS, KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, n, g KX_BFWD);
     }
   }
 
@@ -423,16 +427,16 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     }
     const int hq = kvh * kv_mul + head;
     if (nsplit == 1) {
-      out[(size_t)hq * HS + d] = O / L;
+      *KX_CKP(AB_OUT, out + ((size_t)hq * HS + d)) = O / L;
     } else {
       // write-through (device-scope) stores: visible to the merging workgroup on any XCD without
       // a cache write-back
       float* dst = ws + ((size_t)hq * gridDim.y + split) * attn_ws_stride(HS);
       if (d == 0) {
-        st_device(dst + HS, M);
-        st_device(dst + HS + 1, L);
+        st_device(KX_CKP(AB_WS, dst + HS), M);
+        st_device(KX_CKP(AB_WS, dst + HS + 1), L);
       }
-      st_device(dst + d, O);
+      st_device(KX_CKP(AB_WS, dst + d), O);
     }
   }
   if (nsplit == 1) return;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
 #else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #endif
-    const unsigned old = atomicInc(&tickets[kvh * (kTicketStride / sizeof(unsigned))], (unsigned)nsplit - 1u);  // wraps back to 0
+    const unsigned old = atomicInc(KX_CKP(AB_TICKETS, &tickets[kvh * (kTicketStride / sizeof(unsigned))]), (unsigned)nsplit - 1u);  // wraps back to 0
     sm_last = old == (unsigned)nsplit - 1u;
   }
   __syncthreads();
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       for (int k = 0; k < PASS; ++k) {
         // rows past the last split re-read the last one; their weight below is zero
         const unsigned sp = min(s0 + k * RG + rg, nsplit - 1);
+        KX_TOUCHP(AB_WS, reinterpret_cast<const char*>(ws) + (base + (sp * (unsigned)stride + c4) * 4u), 16);
         ov[k] = ld_device4(ws_rsrc, base + (sp * (unsigned)stride + c4) * 4u);
       }
       if (s0 == 0) {
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
           // unconditional (clamped) loads: a load under a lane test is branched around and
           // waited for on its own, one memory round trip per round
           const int sp = c * 64 + lane;
+          KX_TOUCHP(AB_WS, reinterpret_cast<const char*>(ws) + (base + ((unsigned)min(sp, nsplit - 1) * (unsigned)stride + HS) * 4u), 8);
           const float2 ml =
               ld_device2(ws_rsrc, base + ((unsigned)min(sp, nsplit - 1) * (unsigned)stride + HS) * 4u);
           m[c] = sp < nsplit ? ml.x : -INFINITY;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       acc.z += __shfl_xor(acc.z, off);
       acc.w += __shfl_xor(acc.w, off);
     }
-    if (rg == 0) *reinterpret_cast<f32x4*>(out + (size_t)(kvh * kv_mul + head) * HS + c4) = acc;
+    if (rg == 0) *KX_CKP(AB_OUT, reinterpret_cast<f32x4*>(out + (size_t)(kvh * kv_mul + head) * HS + c4)) = acc;
   }
   stamp(5);  // this wave's heads merged
 }
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
 __global__ void attn_decode_generic_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                            const float* __restrict__ vc, float* __restrict__ out,
                                            float* __restrict__ score, int last, int kv_mul,
-                                           int kv_dim, int hs, int seq_len, float scale) {
+                                           int kv_dim, int hs, int seq_len, float scale KX_BPARAM(7)) {
   __shared__ float red[16];
   const int h = blockIdx.x;
   const float* qh = q + (size_t)h * hs;
@@ -556,9 +562,9 @@ __global__ void attn_decode_generic_kernel(const float* __restrict__ q, const fl
   for (int t = threadIdx.x; t <= last; t += blockDim.x) {
     const float* kr = kc + (size_t)t * kv_dim + hoff;
     float acc = 0.f;
-    for (int d = 0; d < hs; ++d) acc = fmaf(qh[d], kr[d], acc);
+    for (int d = 0; d < hs; ++d) acc = fmaf(*KX_CKP(AB_Q, qh + d), *KX_CKP(AB_K, kr + d), acc);
     acc *= scale;
-    sc[t] = acc;
+    *KX_CKP(AB_WS, sc + t) = acc;
     mx = fmaxf(mx, acc);
   }
   mx = wave_max(mx);
@@ -569,8 +575,8 @@ __global__ void attn_decode_generic_kernel(const float* __restrict__ q, const fl
   __syncthreads();
   float sum = 0.f;
   for (int t = threadIdx.x; t <= last; t += blockDim.x) {
-    const float e = expf(sc[t] - mx);
-    sc[t] = e;
+    const float e = expf(*KX_CKP(AB_WS, sc + t) - mx);
+    *KX_CKP(AB_WS, sc + t) = e;
     sum += e;
   }
   sum = wave_sum(sum);
@@ -580,8 +586,8 @@ __global__ void attn_decode_generic_kernel(const float* __restrict__ q, const fl
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[w];
   for (int d = threadIdx.x; d < hs; d += blockDim.x) {
     float acc = 0.f;
-    for (int t = 0; t <= last; ++t) acc = fmaf(sc[t], vc[(size_t)t * kv_dim + hoff + d], acc);
-    out[(size_t)h * hs + d] = acc / sum;
+    for (int t = 0; t <= last; ++t) acc = fmaf(*KX_CKP(AB_WS, sc + t), *KX_CKP(AB_V, vc + ((size_t)t * kv_dim + hoff + d)), acc);
+    *KX_CKP(AB_OUT, out + ((size_t)h * hs + d)) = acc / sum;
   }
 }
 
@@ -623,7 +629,8 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
                        (hipStream_t)stream, query, reinterpret_cast<const float*>(kc),
                        reinterpret_cast<const float*>(vc), out,
                        reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes), pos,
-                       kv_mul, kv_dim, head_size, seq_len, scale);
+                       kv_mul, kv_dim, head_size, seq_len, scale
+                       KX_BPASS(7, query, kc, vc, out, workspace, nullptr, nullptr));
     KX_LAUNCH_CHECK();
     return KX_OK;
   }
@@ -668,10 +675,12 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   do {                                                                                           \
     if (prefetch)                                                                                \
       hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace);                 \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace             \
+                         KX_BPASS(7, query, kc, vc, out, ws, tickets, pos_dev));                        \
     else                                                                                         \
       hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace);                 \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace             \
+                         KX_BPASS(7, query, kc, vc, out, ws, tickets, pos_dev));                        \
   } while (0)
   // up to four query heads per kv head: the 4x4x1 form of the matrix instruction (a quarter of
   // the matrix-core cycles of the 16-column form, which leaves 12 head columns idle)
@@ -718,7 +727,8 @@ extern "C" int kx_mha_decode_scores_f32(const float* query, const float* key_cac
     const size_t layer_off = (size_t)layer_index * (size_t)seq_len * (size_t)kv_dim;
     hipLaunchKernelGGL(attn_decode_generic_kernel, dim3(head_num), dim3(256), 0, (hipStream_t)stream,
                        query, key_cache + layer_off, value_cache + layer_off, out, score, pos, kv_mul,
-                       kv_dim, head_size, seq_len, 1.0f / sqrtf((float)head_size));
+                       kv_dim, head_size, seq_len, 1.0f / sqrtf((float)head_size)
+                       KX_BPASS(7, query, key_cache, value_cache, out, score, nullptr, nullptr));
     KX_LAUNCH_CHECK();
     return KX_OK;
   }
@@ -786,6 +796,9 @@ extern "C" int kx_mha_decode_static_f32(const float* query, const float* key_cac
       KX_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
       if (!p) return KX_EINVAL;
       g_scratch_ptr[dev] = p;
+#ifdef KX_BOUNDS
+      kx::bounds_track(p, kStaticScratchBytes);  // the array is a block like any other to the checks
+#endif
     }
     ptr = g_scratch_ptr[dev];
   }

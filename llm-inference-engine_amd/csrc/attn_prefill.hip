@@ -28,6 +28,7 @@
 
 #include <type_traits>
 
+#define KX_FILE_ID 6
 #include "kx_common.hpp"
 
 namespace kx {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void kv_to_f16_kernel(const KVT* __restrict__ 
                                                         const KVT* __restrict__ vc,
                                                         _Float16* __restrict__ k16,
                                                         _Float16* __restrict__ v16t, int kv_dim,
-                                                        int pos, int s_pad) {
+                                                        int pos, int s_pad KX_BPARAM(4)) {
   constexpr int VROW = HS + 2;  // halves per LDS row: odd word stride for the column gathers
   __shared__ _Float16 vt[FA_KV * VROW];
   const int tid = threadIdx.x;
@@ -63,11 +64,11 @@ __global__ __launch_bounds__(256) void kv_to_f16_kernel(const KVT* __restrict__ 
   for (int item = tid; item < FA_KV * (HS / 4); item += 256) {
     const int key = item / (HS / 4), d4 = (item % (HS / 4)) * 4;
     const size_t src = (size_t)min(key0 + key, pos) * kv_dim + (size_t)kvh * HS + d4;
-    const f32x4 kv = fa_load4(kc + src);
-    const f32x4 vv = fa_load4(vc + src);
+    const f32x4 kv = fa_load4(KX_CKPN(0, kc + src, 4 * sizeof(KVT)));
+    const f32x4 vv = fa_load4(KX_CKPN(1, vc + src, 4 * sizeof(KVT)));
     f16x4 h;
     h[0] = sat_f16(kv.x); h[1] = sat_f16(kv.y); h[2] = sat_f16(kv.z); h[3] = sat_f16(kv.w);
-    *reinterpret_cast<f16x4*>(k16 + ((size_t)kvh * s_pad + key0 + key) * HS + d4) = h;
+    *KX_CKP(2, reinterpret_cast<f16x4*>(k16 + ((size_t)kvh * s_pad + key0 + key) * HS + d4)) = h;
     _Float16* row = vt + key * VROW + d4;
     row[0] = sat_f16(vv.x); row[1] = sat_f16(vv.y); row[2] = sat_f16(vv.z); row[3] = sat_f16(vv.w);
   }
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void kv_to_f16_kernel(const KVT* __restrict__ 
     f16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = vt[fa_key_of_pos(8 * c + j) * VROW + d];
-    *reinterpret_cast<f16x8*>(v16t + ((size_t)kvh * HS + d) * s_pad + key0 + 8 * c) = o;
+    *KX_CKP(3, reinterpret_cast<f16x8*>(v16t + ((size_t)kvh * HS + d) * s_pad + key0 + 8 * c)) = o;
   }
 }
 
@@ -96,7 +97,9 @@ struct FaArgs {
   const _Float16* kc16;  // 16-bit cache: the layer's rows (kc / vc are null then)
   const _Float16* vc16;
   int32_t s_pad;
+  KX_BFIELD(7)  // operands of the bounds-checking build, in the order of FaOperand
 };
+enum FaOperand { PB_Q, PB_KC, PB_VC, PB_OUT, PB_OUT16, PB_K16, PB_V16T };
 
 #ifdef FA_TRACE
 // diagnostic build only (tools/fa_trace.py): cycles per loop phase of the heaviest workgroup
@@ -120,9 +123,9 @@ __device__ unsigned long long fa_trace_buf[8][16];
 // chunk c of a row sits at chunk position c ^ key(row) (the K image's rule), so the reads of 16
 // consecutive lanes -- one row segment, or two -- cover the banks once.
 template <int HS, typename OutT>
-__device__ __forceinline__ void fa_store_rows(char* region, const f32x16 (&o)[HS / 32], float inv,
-                                              OutT* out_row0, size_t row_stride, int rows_valid,
-                                              int lane) {
+__device__ __forceinline__ void fa_store_rows(const FaArgs& a, int operand, char* region,
+                                              const f32x16 (&o)[HS / 32], float inv, OutT* out_row0,
+                                              size_t row_stride, int rows_valid, int lane) {
   constexpr int ES = sizeof(OutT);
   constexpr int SEG = HS * ES < 256 ? HS * ES : 256;  // bytes per row and round
   constexpr int C = SEG / 16;                          // chunks per row segment
@@ -157,8 +160,8 @@ __device__ __forceinline__ void fa_store_rows(char* region, const f32x16 (&o)[HS
       const int rkey = (row * C / 16) % C;
       const i32x4 val = *reinterpret_cast<const i32x4*>(region + row * SEG + ((c ^ rkey) << 4));
       if (row < rows_valid)
-        *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(out_row0 + (size_t)row * row_stride) +
-                                  r * SEG + c * 16) = val;
+        *KX_CK(a, operand, reinterpret_cast<i32x4*>(reinterpret_cast<char*>(out_row0 + (size_t)row * row_stride) +
+                                                    r * SEG + c * 16)) = val;
     }
   }
 }
@@ -251,9 +254,9 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     if (wave >= NW) return;
 #pragma unroll
     for (int i = 0; i < DPER; ++i)
-      __builtin_amdgcn_global_load_lds(dbase[i] + (doff[i] + (unsigned)t * dstep[i]),
-                                       (lds_ptr_t)(smem + buf * DBUF_B + (wave + NW * i) * 1024), 16, 0,
-                                       0);
+      __builtin_amdgcn_global_load_lds(
+          KX_CKN(a, (wave % NW + NW * i) < DK_PIECES ? PB_K16 : PB_V16T, dbase[i] + (doff[i] + (unsigned)t * dstep[i]), 16),
+          (lds_ptr_t)(smem + buf * DBUF_B + (wave + NW * i) * 1024), 16, 0, 0);
   };
   if constexpr (DMA) issue_tile(0, 0);
   // Waves 4..7 of an eight-wave workgroup are the later-dispatched wave of each SIMD and lose the
@@ -273,8 +276,8 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     f32x4 qraw[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      qraw[ks][0] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
-      qraw[ks][1] = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+      qraw[ks][0] = *KX_CK(a, PB_Q, reinterpret_cast<const f32x4*>(qp + 16 * ks));
+      qraw[ks][1] = *KX_CK(a, PB_Q, reinterpret_cast<const f32x4*>(qp + 16 * ks + 4));
     }
     const float qscale = my_row < a.Tq ? qscale_all : 0.f;
 #pragma unroll
@@ -335,8 +338,8 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
       const int item = tid + i * nthreads;
       if (item < K_ITEMS) {
         const int key = item / (HS / 4), dg = item % (HS / 4);
-        kreg[i] = *reinterpret_cast<const f32x4*>(
-            kbase + (size_t)min(key0 + key, a.pos) * a.kv_dim + 4 * dg);
+        kreg[i] = *KX_CK(a, PB_KC, reinterpret_cast<const f32x4*>(
+            kbase + (size_t)min(key0 + key, a.pos) * a.kv_dim + 4 * dg));
       }
     }
 #pragma unroll
@@ -346,8 +349,8 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
         const int kg = item / (HS / 4), dg = item % (HS / 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          vreg[i][e] = *reinterpret_cast<const f32x4*>(
-              vbase + (size_t)min(key0 + 4 * kg + e, a.pos) * a.kv_dim + 4 * dg);
+          vreg[i][e] = *KX_CK(a, PB_VC, reinterpret_cast<const f32x4*>(
+              vbase + (size_t)min(key0 + 4 * kg + e, a.pos) * a.kv_dim + 4 * dg));
       }
     }
   };
@@ -637,14 +640,14 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
     if (a.out16) {
       constexpr int RB = 32 * (HS * 2 < 256 ? HS * 2 : 256);
       if (nwaves * RB <= 2 * DBUF_B) {
-        fa_store_rows<HS, _Float16>(smem + wave * RB, o, inv, a.out16 + head_off, (size_t)a.H * HS,
+        fa_store_rows<HS, _Float16>(a, PB_OUT16, smem + wave * RB, o, inv, a.out16 + head_off, (size_t)a.H * HS,
                                     rows_valid, lane);
         stored = true;
       }
     } else {
       constexpr int RB = 32 * (HS * 4 < 256 ? HS * 4 : 256);
       if (nwaves * RB <= 2 * DBUF_B) {
-        fa_store_rows<HS, float>(smem + wave * RB, o, inv, a.out + head_off, (size_t)a.H * HS, rows_valid,
+        fa_store_rows<HS, float>(a, PB_OUT, smem + wave * RB, o, inv, a.out + head_off, (size_t)a.H * HS, rows_valid,
                                  lane);
         stored = true;
       }
@@ -661,9 +664,9 @@ __device__ __forceinline__ void attn_prefill_body(const FaArgs& a) {
         if (a.out16) {
           f16x4 h;
           h[0] = sat_f16(v.x); h[1] = sat_f16(v.y); h[2] = sat_f16(v.z); h[3] = sat_f16(v.w);
-          *reinterpret_cast<f16x4*>(a.out16 + off + 32 * dt + 8 * g) = h;
+          *KX_CK(a, PB_OUT16, reinterpret_cast<f16x4*>(a.out16 + off + 32 * dt + 8 * g)) = h;
         } else {
-          *reinterpret_cast<f32x4*>(a.out + off + 32 * dt + 8 * g) = v;
+          *KX_CK(a, PB_OUT, reinterpret_cast<f32x4*>(a.out + off + 32 * dt + 8 * g)) = v;
         }
       }
   }
@@ -707,14 +710,15 @@ static int launch_prefill(FaArgs a, int kvh, int threads, int qblocks, void* wor
     _Float16* v16t = reinterpret_cast<_Float16*>(ws + half_bytes);
     if (a.kc16)
       hipLaunchKernelGGL((kv_to_f16_kernel<HS, _Float16>), dim3(s_pad / FA_KV, kvh), dim3(256), 0, s,
-                         a.kc16, a.vc16, k16, v16t, a.kv_dim, a.pos, s_pad);
+                         a.kc16, a.vc16, k16, v16t, a.kv_dim, a.pos, s_pad KX_BPASS(4, a.kc16, a.vc16, k16, v16t));
     else
       hipLaunchKernelGGL((kv_to_f16_kernel<HS, float>), dim3(s_pad / FA_KV, kvh), dim3(256), 0, s, a.kc,
-                         a.vc, k16, v16t, a.kv_dim, a.pos, s_pad);
+                         a.vc, k16, v16t, a.kv_dim, a.pos, s_pad KX_BPASS(4, a.kc, a.vc, k16, v16t));
     KX_LAUNCH_CHECK();
     a.k16 = k16;
     a.v16t = v16t;
     a.s_pad = s_pad;
+    KX_BSET(a, PB_K16, a.k16); KX_BSET(a, PB_V16T, a.v16t);
     return launch_prefill_kernel<HS, true>(a, kvh, threads, qblocks, s);
   }
   return launch_prefill_kernel<HS, false>(a, kvh, threads, qblocks, s);
@@ -807,6 +811,8 @@ static int flash_attention_run(const float* query, const void* key_cache_any,
   a.Tq = Tq; a.H = head_num; a.kv_mul = kv_mul; a.kv_dim = kv_dim; a.pos = pos;
   a.causal = is_causal ? 1 : 0; a.hpb = hpb; a.qsubs = qsubs; a.scale = softmax_scale;
   const int qblocks = (Tq + 32 * qsubs - 1) / (32 * qsubs);
+  KX_BSET(a, PB_Q, a.q); KX_BSET(a, PB_KC, a.kc); KX_BSET(a, PB_VC, a.vc); KX_BSET(a, PB_OUT, a.out);
+  KX_BSET(a, PB_OUT16, a.out16); KX_BSET(a, PB_K16, nullptr); KX_BSET(a, PB_V16T, nullptr);
   hipStream_t s = (hipStream_t)stream;
   switch (head_size) {
     case 32: return launch_prefill<32>(a, kv_head_num, threads, qblocks, workspace, workspace_bytes, s);

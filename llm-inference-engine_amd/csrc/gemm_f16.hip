@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#define KX_FILE_ID 4
 #include "kx_common.hpp"
 
 namespace kx {
@@ -46,20 +47,22 @@ struct GemmF16Args {
   const float* sin_cache;  // [position][head_size], the entry of a pair at its even index
   const float* cos_cache;
   int32_t rope_variant, head_size, pos0;  // rope_variant < 0: bias only
+  KX_BFIELD(13)  // operands of the bounds-checking build, in the order of GemmF16Operand
 };
+enum GemmF16Operand { FB_X, FB_W, FB_COLF, FB_RES, FB_H16, FB_Y0, FB_Y1, FB_Y2, FB_SLABS, FB_TICKETS, FB_BIAS, FB_SIN, FB_COS };
 
 // X fp32 [T][ldx] -> fp16 [T][ldy], M columns
 __global__ void f32_to_f16_rows_kernel(const float* __restrict__ x, int64_t ldx,
-                                       _Float16* __restrict__ y, int64_t ldy, int M, int64_t n4) {
+                                       _Float16* __restrict__ y, int64_t ldy, int M, int64_t n4 KX_BPARAM(2)) {
   const int m4 = M / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / m4;
     const int c = (int)(i - t * m4) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * ldx + c);
+    const f32x4 v = *KX_CKP(0, reinterpret_cast<const f32x4*>(x + t * ldx + c));
     f16x4 h;
     h[0] = sat_f16(v.x); h[1] = sat_f16(v.y); h[2] = sat_f16(v.z); h[3] = sat_f16(v.w);
-    *reinterpret_cast<f16x4*>(y + t * ldy + c) = h;
+    *KX_CKP(1, reinterpret_cast<f16x4*>(y + t * ldy + c)) = h;
   }
 }
 
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
                                                               const float* __restrict__ scales,
                                                               _Float16* __restrict__ w16,
                                                               float* __restrict__ colf, int M, int K,
-                                                              int gs_shift, int swiglu_half) {
+                                                              int gs_shift, int swiglu_half KX_BPARAM(4)) {
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= K) return;
@@ -83,17 +86,17 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
   const int groups = M >> gs_shift;
   const float* sp = scales + (size_t)p * groups;
   float mx = 0.f;
-  for (int g = lane; g < groups; g += 64) mx = fmaxf(mx, fabsf(sp[g]));
+  for (int g = lane; g < groups; g += 64) mx = fmaxf(mx, fabsf(*KX_CKP(1, sp + g)));
   mx = wave_max(mx) * 127.0f;
   // smallest power of two >= the row's largest scaled weight (1 for an all-zero row)
   const float f = mx > 0.f ? exp2f(ceilf(log2f(mx))) : 1.0f;
   const float inv = 1.0f / f;
-  if (lane == 0) colf[q] = f;
+  if (lane == 0) *KX_CKP(3, colf + q) = f;
   const int8_t* wp = w + (size_t)p * M;
   _Float16* op = w16 + (size_t)q * M;
   for (int c = lane * 16; c < M; c += 1024) {
-    const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + c));
-    const float s = sp[c >> gs_shift] * inv;
+    const i32x4 v = __builtin_nontemporal_load(KX_CKP(0, reinterpret_cast<const i32x4*>(wp + c)));
+    const float s = *KX_CKP(1, sp + (c >> gs_shift)) * inv;
     const int32_t words[4] = {v.x, v.y, v.z, v.w};
     f16x8 lo, hi;
 #pragma unroll
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(256) void w8_dequant_rows_kernel(const int8_t* __re
       hi[e] = (_Float16)((float)(int8_t)(words[2] >> (8 * e)) * s);
       hi[4 + e] = (_Float16)((float)(int8_t)(words[3] >> (8 * e)) * s);
     }
-    *reinterpret_cast<f16x8*>(op + c) = lo;
-    *reinterpret_cast<f16x8*>(op + c + 8) = hi;
+    *KX_CKP(2, reinterpret_cast<f16x8*>(op + c)) = lo;
+    *KX_CKP(2, reinterpret_cast<f16x8*>(op + c + 8)) = hi;
   }
 }
 
@@ -133,7 +136,7 @@ __device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f3
       const int n = ncol0 + ni * 32 + frow;  // gate row in the interleaved order
       if (n >= a.K) continue;
       const int j = (n >> 6) * 32 + frow;                // hidden unit
-      const float fg = a.colf[n], fu = a.colf[n + 32];
+      const float fg = *KX_CK(a, FB_COLF, a.colf + n), fu = *KX_CK(a, FB_COLF, a.colf + (n + 32));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -141,7 +144,7 @@ __device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f3
           const int t = trow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (t < a.T) {
             const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 1][r] * fu;
-            a.h16[(size_t)t * half_k + j] = sat_f16(silu_mul_fast(g, u));
+            *KX_CK(a, FB_H16, a.h16 + ((size_t)t * half_k + j)) = sat_f16(silu_mul_fast(g, u));
           }
         }
     }
@@ -151,17 +154,18 @@ __device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f3
   for (int ni = 0; ni < NI; ++ni) {
     const int n = ncol0 + ni * 32 + frow;
     if (n >= a.K) continue;
-    const float f = a.colf[n];
+    const float f = *KX_CK(a, FB_COLF, a.colf + n);
     float* dst;
     int64_t ld;
     int col;
+    [[maybe_unused]] int op;
     bool add_res = false;
     if (n < a.k0) {
-      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr; op = FB_Y0;
     } else if (n < a.k1) {
-      dst = a.y1; ld = a.ld1; col = n - a.k0;
+      dst = a.y1; ld = a.ld1; col = n - a.k0; op = FB_Y1;
     } else {
-      dst = a.y2; ld = a.ld2; col = n - a.k1;
+      dst = a.y2; ld = a.ld2; col = n - a.k1; op = FB_Y2;
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -170,8 +174,8 @@ __device__ __forceinline__ void gemm_f16_epilogue(const GemmF16Args& a, const f3
         const int t = trow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (t < a.T) {
           float v = acc[mi][ni][r] * f;
-          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
-          dst[(size_t)t * ld + col] = v;
+          if (add_res) v += *KX_CK(a, FB_RES, a.residual + ((size_t)t * a.ldr + col));
+          *KX_CK(a, op, dst + ((size_t)t * ld + col)) = v;
         }
       }
   }
@@ -193,7 +197,7 @@ __device__ __forceinline__ void gemm_f16_epilogue16(const GemmF16Args& a, const 
       const int n = ncol0 + ni * 16 + fcol;  // gate row in the interleaved order
       if (n >= a.K) continue;
       const int j = (n >> 6) * 32 + (n & 31);  // hidden unit
-      const float fg = a.colf[n], fu = a.colf[n + 32];
+      const float fg = *KX_CK(a, FB_COLF, a.colf + n), fu = *KX_CK(a, FB_COLF, a.colf + (n + 32));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -201,7 +205,7 @@ __device__ __forceinline__ void gemm_f16_epilogue16(const GemmF16Args& a, const 
           const int t = trow0 + mi * 16 + frow4 + r;
           if (t < a.T) {
             const float g = acc[mi][ni][r] * fg, u = acc[mi][ni + 2][r] * fu;
-            a.h16[(size_t)t * half_k + j] = sat_f16(silu_mul_fast(g, u));
+            *KX_CK(a, FB_H16, a.h16 + ((size_t)t * half_k + j)) = sat_f16(silu_mul_fast(g, u));
           }
         }
     }
@@ -211,17 +215,18 @@ __device__ __forceinline__ void gemm_f16_epilogue16(const GemmF16Args& a, const 
   for (int ni = 0; ni < NI; ++ni) {
     const int n = ncol0 + ni * 16 + fcol;
     if (n >= a.K) continue;
-    const float f = a.colf[n];
+    const float f = *KX_CK(a, FB_COLF, a.colf + n);
     float* dst;
     int64_t ld;
     int col;
+    [[maybe_unused]] int op;
     bool add_res = false;
     if (n < a.k0) {
-      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr; op = FB_Y0;
     } else if (n < a.k1) {
-      dst = a.y1; ld = a.ld1; col = n - a.k0;
+      dst = a.y1; ld = a.ld1; col = n - a.k0; op = FB_Y1;
     } else {
-      dst = a.y2; ld = a.ld2; col = n - a.k1;
+      dst = a.y2; ld = a.ld2; col = n - a.k1; op = FB_Y2;
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -230,8 +235,8 @@ __device__ __forceinline__ void gemm_f16_epilogue16(const GemmF16Args& a, const 
         const int t = trow0 + mi * 16 + frow4 + r;
         if (t < a.T) {
           float v = acc[mi][ni][r] * f;
-          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
-          dst[(size_t)t * ld + col] = v;
+          if (add_res) v += *KX_CK(a, FB_RES, a.residual + ((size_t)t * a.ldr + col));
+          *KX_CK(a, op, dst + ((size_t)t * ld + col)) = v;
         }
       }
   }
@@ -302,11 +307,11 @@ __device__ __forceinline__ void gemm_f16_body(const GemmF16Args& a) {
   for (int ks = 0; ks < ksteps; ++ks) {
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_global_load_lds(asrc[i] + ks * GF_BK,
+      __builtin_amdgcn_global_load_lds(KX_CKN(a, FB_X, asrc[i] + ks * GF_BK, 16),
                                        (lds_ptr_t)(smem + (4 * i + wave) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      __builtin_amdgcn_global_load_lds(bsrc[i] + ks * GF_BK,
+      __builtin_amdgcn_global_load_lds(KX_CKN(a, FB_W, bsrc[i] + ks * GF_BK, 16),
                                        (lds_ptr_t)(smem + A_BYTES + (4 * i + wave) * 1024), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -374,11 +379,11 @@ struct GemmPipeCtx {
 };
 
 template <int PIECE, int BUFSEL>
-__device__ __forceinline__ void gp_issue(char* smem, const GemmPipeCtx& c, int tile) {
+__device__ __forceinline__ void gp_issue(const GemmF16Args& a, char* smem, const GemmPipeCtx& c, int tile) {
   const int koff = min(tile, c.nt - 1) * GF_BK;
 #pragma unroll
   for (int j = 0; j < 2; ++j)
-    __builtin_amdgcn_global_load_lds(c.src[PIECE][j] + koff,
+    __builtin_amdgcn_global_load_lds(KX_CKN(a, (PIECE & 1) ? FB_X : FB_W, c.src[PIECE][j] + koff, 16),
                                      (gp_lds_ptr_t)(smem + BUFSEL * GP_BUF + c.dst[PIECE][j]), 16, 0, 0);
 }
 
@@ -397,7 +402,7 @@ __device__ __forceinline__ void gp_read16(const char* smem, int base, const int 
 // quadrant's 16 MFMAs (row blocks MI0 .. MI0 + 3 x column blocks NI0, NI0 + 1), barrier.  The
 // priority pair keeps the compiler from moving MFMAs across the barriers in among the loads.
 #define GP_PHASE(PIECE, BUFSEL, TILE, MI0, NI0, BREG, LIVE)                                             \
-  gp_issue<PIECE, BUFSEL>(smem, c, TILE);                                                               \
+  gp_issue<PIECE, BUFSEL>(a, smem, c, TILE);                                                            \
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_barrier();                                                                         \
@@ -422,7 +427,7 @@ __device__ __forceinline__ void gp_read16(const char* smem, int base, const int 
 // halves hold no real row skip the fragment reads and the MFMAs of those halves -- the matrix pipe
 // stops setting the pace of a K-tile step, the weight stream does.
 template <int PAR, bool SHORT>
-__device__ __forceinline__ void gp_tile(char* smem, const GemmPipeCtx& c, int t, f32x4 (&acc)[8][4],
+__device__ __forceinline__ void gp_tile(const GemmF16Args& a, char* smem, const GemmPipeCtx& c, int t, f32x4 (&acc)[8][4],
                                         f16x8 (&af)[4][2], f16x8 (&bq0)[2][2], f16x8 (&bq1)[2][2]) {
   const bool lo = SHORT ? c.live_lo : true, hi = SHORT ? c.live_hi : true;
   // phase 0: rows 0-63 of the wave tile x columns 0-31
@@ -463,7 +468,7 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int n = ncol0 + ni * 16 + c16;
-      const float fg = n < a.K ? a.colf[n] : 0.f, fu = n < a.K ? a.colf[n + 32] : 0.f;
+      const float fg = n < a.K ? *KX_CK(a, FB_COLF, a.colf + n) : 0.f, fu = n < a.K ? *KX_CK(a, FB_COLF, a.colf + (n + 32)) : 0.f;
       const int unit = wc * 32 + ni * 16 + c16;
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
@@ -481,7 +486,7 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
     for (int it = 0; it < 8; ++it) {
       const int row = wave * 32 + it * 4 + g, t = tile_row0 + row, j = tile_j0 + c16 * 8;
       const f16x8 v = *reinterpret_cast<const f16x8*>(wb + row * 128 + ((c16 ^ (row & 15)) << 3));
-      if (t < a.T && j < half_k) *reinterpret_cast<f16x8*>(a.h16 + (size_t)t * half_k + j) = v;
+      if (t < a.T && j < half_k) *KX_CK(a, FB_H16, reinterpret_cast<f16x8*>(a.h16 + (size_t)t * half_k + j)) = v;
     }
     return;
   } else {
@@ -490,21 +495,22 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = ncol0 + ni * 16 + c16;
-      f[ni] = n < a.K ? a.colf[n] : 0.f;
-      bias[ni] = ROPE && a.bias && n < a.K ? a.bias[n] : 0.f;
+      f[ni] = n < a.K ? *KX_CK(a, FB_COLF, a.colf + n) : 0.f;
+      bias[ni] = ROPE && a.bias && n < a.K ? *KX_CK(a, FB_BIAS, a.bias + n) : 0.f;
     }
     // this lane's four columns when reading back, and where they go
     const int n4 = ncol0 + 4 * c16;
     float* dst;
     int64_t ld;
     int col;
+    [[maybe_unused]] int op;
     bool add_res = false;
     if (n4 < a.k0) {
-      dst = a.y0; ld = a.ld0; col = n4; add_res = a.residual != nullptr;
+      dst = a.y0; ld = a.ld0; col = n4; add_res = a.residual != nullptr; op = FB_Y0;
     } else if (n4 < a.k1) {
-      dst = a.y1; ld = a.ld1; col = n4 - a.k0;
+      dst = a.y1; ld = a.ld1; col = n4 - a.k0; op = FB_Y1;
     } else {
-      dst = a.y2; ld = a.ld2; col = n4 - a.k1;
+      dst = a.y2; ld = a.ld2; col = n4 - a.k1; op = FB_Y2;
     }
     // rotary embedding (ROPE form): the columns of q and k turn with their pair partner.  Pairs
     // are (2i, 2i+1) of a head (interleaved, rope_kernel.cu:98-128) or (i, i + hs/2) (half-split,
@@ -540,26 +546,26 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
           const size_t trow = (size_t)(a.pos0 + min(t, a.T - 1)) * a.head_size + tab;
           if (split) {
             const f32x4 pv = *reinterpret_cast<const f32x4*>(pb + row * 64 + (pcol ^ sw));
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.sin_cache + trow);
-            const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.sin_cache + trow + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.cos_cache + trow);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.cos_cache + trow + 4);
+            const f32x4 s0 = *KX_CK(a, FB_SIN, reinterpret_cast<const f32x4*>(a.sin_cache + trow));
+            const f32x4 s1 = *KX_CK(a, FB_SIN, reinterpret_cast<const f32x4*>(a.sin_cache + trow + 4));
+            const f32x4 c0 = *KX_CK(a, FB_COS, reinterpret_cast<const f32x4*>(a.cos_cache + trow));
+            const f32x4 c1 = *KX_CK(a, FB_COS, reinterpret_cast<const f32x4*>(a.cos_cache + trow + 4));
             const f32x4 sn = {s0.x, s0.z, s1.x, s1.z}, cs = {c0.x, c0.z, c1.x, c1.z};
             // x_lo' = x_lo cos - x_hi sin ; x_hi' = x_lo sin + x_hi cos
             v = low ? v * cs - pv * sn : pv * sn + v * cs;
           } else {
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.sin_cache + trow);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.cos_cache + trow);
+            const f32x4 s0 = *KX_CK(a, FB_SIN, reinterpret_cast<const f32x4*>(a.sin_cache + trow));
+            const f32x4 c0 = *KX_CK(a, FB_COS, reinterpret_cast<const f32x4*>(a.cos_cache + trow));
             v = f32x4{v.x * c0.x - v.y * s0.x, v.x * s0.x + v.y * c0.x,
                       v.z * c0.z - v.w * s0.z, v.z * s0.z + v.w * c0.z};
           }
         }
         if (t < a.T && n4 < a.K) {
           if (add_res) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + (size_t)t * a.ldr + col);
+            const f32x4 rv = *KX_CK(a, FB_RES, reinterpret_cast<const f32x4*>(a.residual + (size_t)t * a.ldr + col));
             v += rv;
           }
-          *reinterpret_cast<f32x4*>(dst + (size_t)t * ld + col) = v;
+          *KX_CK(a, op, reinterpret_cast<f32x4*>(dst + (size_t)t * ld + col)) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites
@@ -573,8 +579,8 @@ __device__ __forceinline__ void gemm_pipe_epilogue_lds(const GemmF16Args& a, con
 // the unrolled loop lets the next blocks' loads go out under the sums.  Row blocks past the last
 // row (`live` blocks of 16 rows in this wave's tile) were never stored and are skipped.
 template <int S>
-__device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t rs, unsigned lane_off,
-                                           int live) {
+__device__ __forceinline__ void gp_combine(const GemmF16Args& a, const char* slab_base, f32x4 (&acc)[8][4],
+                                           __amdgpu_buffer_rsrc_t rs, unsigned lane_off, int live) {
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     if (mi >= live) break;
@@ -582,9 +588,11 @@ __device__ __forceinline__ void gp_combine(f32x4 (&acc)[8][4], __amdgpu_buffer_r
     for (int ni = 0; ni < 4; ++ni) {
       u32x4 v[S];
 #pragma unroll
-      for (int pp = 0; pp < S; ++pp)
-        v[pp] = __builtin_amdgcn_raw_buffer_load_b128(
-            rs, (unsigned)pp * 262144u + lane_off + (mi * 4 + ni) * 1024, 0, 16);
+      for (int pp = 0; pp < S; ++pp) {
+        const unsigned off = (unsigned)pp * 262144u + lane_off + (mi * 4 + ni) * 1024;
+        KX_TOUCH(a, FB_SLABS, slab_base + off, 16);
+        v[pp] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+      }
       f32x4 t = {__uint_as_float(v[0].x), __uint_as_float(v[0].y), __uint_as_float(v[0].z),
                  __uint_as_float(v[0].w)};
 #pragma unroll
@@ -670,24 +678,24 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
 
   if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
   // prologue: phases -6 .. -2 issue five pieces, phase -1 reads column block 0 of tile 0
-  gp_issue<0, 0>(smem, c, 0);
-  gp_issue<1, 0>(smem, c, 0);
-  gp_issue<2, 0>(smem, c, 0);
-  gp_issue<3, 0>(smem, c, 0);
-  gp_issue<0, 1>(smem, c, 1);
+  gp_issue<0, 0>(a, smem, c, 0);
+  gp_issue<1, 0>(a, smem, c, 0);
+  gp_issue<2, 0>(a, smem, c, 0);
+  gp_issue<3, 0>(a, smem, c, 0);
+  gp_issue<0, 1>(a, smem, c, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_s_barrier();
   gp_read16<0, 0, 2>(smem, c.bbase, c.coff, bx);
-  gp_issue<1, 1>(smem, c, 1);
+  gp_issue<1, 1>(a, smem, c, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_s_barrier();
 
   for (int t = 0; t < c.nt; t += 2) {
-    gp_tile<0, SHORT>(smem, c, t, acc, af, bx, by);
-    if (t + 1 < c.nt) gp_tile<1, SHORT>(smem, c, t + 1, acc, af, by, bx);
+    gp_tile<0, SHORT>(a, smem, c, t, acc, af, bx, by);
+    if (t + 1 < c.nt) gp_tile<1, SHORT>(a, smem, c, t + 1, acc, af, by, bx);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads target this LDS
@@ -697,8 +705,8 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
     // arrival ticket per tile (it wraps back to zero); the workgroup that arrives last adds the
     // parts in index order -- the same sum whichever arrives last -- with device-scope loads
     // and writes the tile.  No workgroup ever waits for another.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.slabs + (size_t)(wgid - a.full_tiles) * nsplit * 65536, 0, (unsigned)nsplit * 262144u, 0x00020000);
+    char* const slab_base = reinterpret_cast<char*>(a.slabs + (size_t)(wgid - a.full_tiles) * nsplit * 65536);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab_base, 0, (unsigned)nsplit * 262144u, 0x00020000);
     const unsigned mine = (unsigned)part * 262144u + (unsigned)(wave * 32 * 1024 + lane * 16);
     // 16-row blocks of this wave's tile that hold real rows (a short prompt fills few of them)
     const int live = min(8, max(0, (a.T - (t0 + wr * 128) + 15) / 16));
@@ -710,13 +718,14 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
         u32x4 v;
         v.x = __float_as_uint(acc[mi][ni][0]); v.y = __float_as_uint(acc[mi][ni][1]);
         v.z = __float_as_uint(acc[mi][ni][2]); v.w = __float_as_uint(acc[mi][ni][3]);
+        KX_TOUCH(a, FB_SLABS, slab_base + (mine + (mi * 4 + ni) * 1024), 16);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + (mi * 4 + ni) * 1024, 0, 16);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // also: every wave is past its last read of the K-tile buffers
     int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) *flag = atomicInc(a.tickets + (wgid - a.full_tiles), (unsigned)nsplit - 1u) == (unsigned)nsplit - 1u;
+    if (tid == 0) *flag = atomicInc(KX_CK(a, FB_TICKETS, a.tickets + (wgid - a.full_tiles)), (unsigned)nsplit - 1u) == (unsigned)nsplit - 1u;
     __syncthreads();
     const int last = *flag;
     if (!last) return;
@@ -729,16 +738,17 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
           if (mi >= live) break;
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                rs, (unsigned)(part ^ 1) * 262144u + lane_off + (mi * 4 + ni) * 1024, 0, 16);
+            const unsigned off = (unsigned)(part ^ 1) * 262144u + lane_off + (mi * 4 + ni) * 1024;
+            KX_TOUCH(a, FB_SLABS, slab_base + off, 16);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
             acc[mi][ni][0] += __uint_as_float(v.x); acc[mi][ni][1] += __uint_as_float(v.y);
             acc[mi][ni][2] += __uint_as_float(v.z); acc[mi][ni][3] += __uint_as_float(v.w);
           }
         }
         break;
-      case 4: gp_combine<4>(acc, rs, lane_off, live); break;
-      case 8: gp_combine<8>(acc, rs, lane_off, live); break;
-      default: gp_combine<16>(acc, rs, lane_off, live); break;
+      case 4: gp_combine<4>(a, slab_base, acc, rs, lane_off, live); break;
+      case 8: gp_combine<8>(a, slab_base, acc, rs, lane_off, live); break;
+      default: gp_combine<16>(a, slab_base, acc, rs, lane_off, live); break;
     }
   }
   if (a.wide_rows) {
@@ -819,6 +829,7 @@ static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_b
   a.tickets = static_cast<unsigned*>(split_ws);
   a.slabs = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitTicketBytes);
   const int grid = a.full_tiles + (tiles - a.full_tiles) * split;
+  KX_BSET(a, FB_SLABS, split_ws ? a.slabs : nullptr); KX_BSET(a, FB_TICKETS, a.tickets);
   hipLaunchKernelGGL(KERN, dim3(grid), dim3(512), 2 * GP_BUF, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
@@ -850,7 +861,7 @@ extern "C" int kx_f32_to_f16_rows(const float* src, int64_t ld_src, void* dst16,
   const int64_t n4 = (int64_t)rows * (cols / 4);
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(kx::f32_to_f16_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
-                     ld_src, static_cast<_Float16*>(dst16), ld_dst, cols, n4);
+                     ld_src, static_cast<_Float16*>(dst16), ld_dst, cols, n4 KX_BPASS(2, src, dst16));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -882,7 +893,7 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   const bool swiglu = mode == KX_GEMM_SWIGLU_F16;
   if (!weights_ready) {
     hipLaunchKernelGGL(w8_dequant_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, w, scales, w16, colf,
-                       M, K, gs_shift, swiglu ? K / 2 : 0);
+                       M, K, gs_shift, swiglu ? K / 2 : 0 KX_BPASS(4, w, scales, w16, colf));
     KX_LAUNCH_CHECK();
   }
   GemmF16Args a{};
@@ -895,6 +906,10 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
     a.bias = qkv_form->bias; a.sin_cache = qkv_form->sin_cache; a.cos_cache = qkv_form->cos_cache;
     a.rope_variant = qkv_form->rope_variant; a.head_size = qkv_form->head_size; a.pos0 = qkv_form->pos0;
   }
+  KX_BSET(a, FB_X, a.X); KX_BSET(a, FB_W, a.W); KX_BSET(a, FB_COLF, a.colf); KX_BSET(a, FB_RES, a.residual);
+  KX_BSET(a, FB_H16, a.h16); KX_BSET(a, FB_Y0, a.y0); KX_BSET(a, FB_Y1, a.y1); KX_BSET(a, FB_Y2, a.y2);
+  KX_BSET(a, FB_SLABS, nullptr); KX_BSET(a, FB_TICKETS, nullptr);
+  KX_BSET(a, FB_BIAS, a.bias); KX_BSET(a, FB_SIN, a.sin_cache); KX_BSET(a, FB_COS, a.cos_cache);
   // Kernel choice (KX_GEMM_F16_KERNEL = 1 / 3 forces one, for A/B runs and tests):
   //   1  128 x 128 tiles, four workgroups per CU      3  pipelined 256 x 256, one per CU
   // The pipelined kernel wins from 512 rows up on every layer matrix of Llama-3-8B, with or
@@ -1017,7 +1032,7 @@ extern "C" int kx_gemm_w8_f32_ws(const float* X, int64_t ldx, const int8_t* w, c
   char* ws = static_cast<char*>(workspace);
   _Float16* x16 = reinterpret_cast<_Float16*>(ws);
   const int64_t n4 = (int64_t)T * (M / 4);
-  hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(2048), dim3(256), 0, s, X, ldx, x16, (int64_t)M, M, n4);
+  hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(2048), dim3(256), 0, s, X, ldx, x16, (int64_t)M, M, n4 KX_BPASS(2, X, x16));
   KX_LAUNCH_CHECK();
   return gemm_f16act_run(x16, w, scales, group_size, KX_GEMM_ROUTE_F32, nullptr, y0, ld0, y1, ld1, y2,
                          ld2, k0, k1, residual, ldr, T, M, K, ws + align256((size_t)T * M * 2), s);

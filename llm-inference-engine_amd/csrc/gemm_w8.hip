@@ -16,6 +16,7 @@
 //   - LDS tiles are [row][64 halves] with rows padded to 144 bytes: the 16-byte fragment reads of
 //     a 16-lane group then fall on distinct banks.  Two LDS buffers, one barrier per K-step, the
 //     next tile's global loads are issued before the MFMAs of the current one.
+#define KX_FILE_ID 3
 #include "kx_common.hpp"
 
 namespace kx {
@@ -32,7 +33,9 @@ struct GemmW8Args {
   int64_t ldx, ld0, ld1, ld2, ldr;
   int32_t k0, k1;
   int32_t T, M, K;
+  KX_BFIELD(7)  // operands of the bounds-checking build, in the order of GemmW8Operand
 };
+enum GemmW8Operand { MB_X, MB_W, MB_S, MB_RES, MB_Y0, MB_Y1, MB_Y2 };
 
 __device__ __forceinline__ f16x8 cvt_i8x8(int32_t lo, int32_t hi) {
   f16x8 r;
@@ -82,14 +85,14 @@ __global__ __launch_bounds__(256, 2) void gemm_w8_kernel(const GemmW8Args a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int t = min(t0 + xr + 16 * i, a.T - 1);
-      xreg[i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)t * a.ldx + kk + xc);
+      xreg[i] = *KX_CK(a, MB_X, reinterpret_cast<const f32x4*>(a.X + (size_t)t * a.ldx + kk + xc));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = min(n0 + wrow + 64 * i, a.K - 1);
-      wreg[i] = *reinterpret_cast<const i32x4*>(a.w + (size_t)n * a.M + kk + wchunk);
+      wreg[i] = *KX_CK(a, MB_W, reinterpret_cast<const i32x4*>(a.w + (size_t)n * a.M + kk + wchunk));
     }
-    if (tid < GM_BN) sreg = a.scales[(size_t)min(n0 + tid, a.K - 1) * groups + g];
+    if (tid < GM_BN) sreg = *KX_CK(a, MB_S, a.scales + ((size_t)min(n0 + tid, a.K - 1) * groups + g));
   };
   auto store_tile = [&](int buf) {
     _Float16* A = lds_a(buf);
@@ -179,13 +182,14 @@ __global__ __launch_bounds__(256, 2) void gemm_w8_kernel(const GemmW8Args a) {
     float* dst;
     int64_t ld;
     int col;
+    [[maybe_unused]] int op;
     bool add_res = false;
     if (n < a.k0) {
-      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr; op = MB_Y0;
     } else if (n < a.k1) {
-      dst = a.y1; ld = a.ld1; col = n - a.k0;
+      dst = a.y1; ld = a.ld1; col = n - a.k0; op = MB_Y1;
     } else {
-      dst = a.y2; ld = a.ld2; col = n - a.k1;
+      dst = a.y2; ld = a.ld2; col = n - a.k1; op = MB_Y2;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_w8_kernel(const GemmW8Args a) {
         const int t = t0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (t < a.T) {
           float v = acc[mi][ni][r];
-          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
-          dst[(size_t)t * ld + col] = v;
+          if (add_res) v += *KX_CK(a, MB_RES, a.residual + ((size_t)t * a.ldr + col));
+          *KX_CK(a, op, dst + ((size_t)t * ld + col)) = v;
         }
       }
   }
@@ -243,6 +247,8 @@ extern "C" int kx_gemm_w8_f32_ex(const float* X, int64_t ldx, const int8_t* w, c
   a.y0 = y0; a.y1 = y1 ? y1 : y0; a.y2 = y2 ? y2 : y0;
   a.ldx = ldx; a.ld0 = ld0; a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr;
   a.k0 = k0; a.k1 = k1; a.T = T; a.M = M; a.K = K;
+  KX_BSET(a, MB_X, a.X); KX_BSET(a, MB_W, a.w); KX_BSET(a, MB_S, a.scales); KX_BSET(a, MB_RES, a.residual);
+  KX_BSET(a, MB_Y0, a.y0); KX_BSET(a, MB_Y1, a.y1); KX_BSET(a, MB_Y2, a.y2);
   return gemm_w8_launch(a, (hipStream_t)stream);
 }
 

@@ -35,6 +35,7 @@
 // fp32 partial tile to a slab with write-through stores, takes an arrival ticket (which wraps back
 // to zero), and the last arriver of a tile adds the parts in index order with device-scope loads
 // and writes the rows -- the same sum whichever part arrives last.
+#define KX_FILE_ID 2
 #include "kx_common.hpp"
 
 namespace kx {
@@ -73,8 +74,10 @@ struct RowsArgs {
   int32_t half;                 //   gate rows [0, half), up rows [half, 2 half)
   const float* sin_cache; const float* cos_cache; const float* bias;  // ROWS_QKV_ROPE
   int32_t head_size, rope_variant, pos0;
+  KX_BFIELD(13)  // operands of the bounds-checking build, in the order of RowsOperand
 };
 enum { ROWS_PLAIN = 0, ROWS_SWIGLU = 1, ROWS_QKV_ROPE = 2 };
+enum RowsOperand { RB_X, RB_W, RB_S, RB_RES, RB_Y0, RB_Y1, RB_Y2, RB_SLABS, RB_TICKETS, RB_H16, RB_SIN, RB_COS, RB_BIAS };
 
 // Which weight rows a compute wave's ring holds: row(rb, i) = base + i * istep + rb * rbstep for row
 // block rb (0, 1) and index i (0..15).  A lane ends up with the totals of rows (0, i) and (1, i) for
@@ -125,8 +128,8 @@ static_assert(4 * (3 - 1) + 2 <= 22, "wait_dma covers the units in flight and th
 
 // TB: token blocks of the tile, TBW: this wave's share of them, starting at block tb0
 template <int S, int TB, int TBW>
-__device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TBW], __amdgpu_buffer_rsrc_t rs, unsigned lane_off,
-                                             int tb0) {
+__device__ __forceinline__ void rows_combine(const RowsArgs& a, const char* slab_base, f32x4 (&acc)[2][TBW],
+                                             __amdgpu_buffer_rsrc_t rs, unsigned lane_off, int tb0) {
   constexpr unsigned PB = TB * 8192u;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
@@ -134,9 +137,11 @@ __device__ __forceinline__ void rows_combine(f32x4 (&acc)[2][TBW], __amdgpu_buff
     for (int tb = 0; tb < TBW; ++tb) {
       u32x4 v[S];
 #pragma unroll
-      for (int p = 0; p < S; ++p)
-        v[p] = __builtin_amdgcn_raw_buffer_load_b128(
-            rs, (unsigned)p * PB + lane_off + (unsigned)((rb * TB + tb0 + tb) * 1024), 0, 16);
+      for (int p = 0; p < S; ++p) {
+        const unsigned off = (unsigned)p * PB + lane_off + (unsigned)((rb * TB + tb0 + tb) * 1024);
+        KX_TOUCH(a, RB_SLABS, slab_base + off, 16);
+        v[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+      }
       f32x4 t = {__uint_as_float(v[0].x), __uint_as_float(v[0].y), __uint_as_float(v[0].z),
                  __uint_as_float(v[0].w)};
 #pragma unroll
@@ -221,7 +226,9 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
 #pragma unroll
           for (int h = 0; h < 2; ++h)
             __builtin_amdgcn_global_load_lds(
-                reinterpret_cast<const uint32_t*>(xbase + (xoff[tb][h] + (unsigned)(u * FR_KU + gl * 64) * 2u)),
+                KX_CKN(a, RB_X,
+                       reinterpret_cast<const uint32_t*>(xbase + (xoff[tb][h] + (unsigned)(u * FR_KU + gl * 64) * 2u)),
+                       16),
                 (lds_ptr_t)(dst + ((gl * TB + tb) * 2 + h) * 1024), 16, 0, 0);
     };
     // unit u + NXB - 1 is requested after the barrier that ends unit u - 1 (whose buffer it takes)
@@ -272,14 +279,16 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           __builtin_amdgcn_global_load_lds(
-              reinterpret_cast<const uint32_t*>(wbase + (woff[rb][h] + (unsigned)u * FR_KU)),
+              KX_CKN(a, RB_W, reinterpret_cast<const uint32_t*>(wbase + (woff[rb][h] + (unsigned)u * FR_KU)), 16),
               (lds_ptr_t)(dst + (rb * 2 + h) * 1024), 16, 0, 2);  // 2 = nt: streamed once
       // the 32 bytes of scales per row that hold this and the next three units' groups, fetched
       // with the first unit of such a block (or of this part)
       const int U = u0 + u;
       if ((U & 3) == 0 || u == 0)
         __builtin_amdgcn_global_load_lds(
-            reinterpret_cast<const uint32_t*>(sbase + (soff + min((unsigned)(U >> 2) * 32u + shalf, srow - 16u))),
+            KX_CKN(a, RB_S,
+                   reinterpret_cast<const uint32_t*>(sbase + (soff + min((unsigned)(U >> 2) * 32u + shalf, srow - 16u))),
+                   16),
             (lds_ptr_t)(sring + ((U >> 2) % FR_SRING) * 1024), 16, 0, 0);
     };
     // fragment addresses: lane (j, q) = (lane & 15, lane >> 4)
@@ -354,8 +363,8 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
   const bool computes = wave < NCW;
   if (nsplit > 1) {
     constexpr unsigned PB = TB * 8192u;  // one part's partial tile: [wave][row block][token block][lane] x 16 B
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(a.slabs) + (size_t)tile * nsplit * PB, 0, (unsigned)nsplit * PB, 0x00020000);
+    char* const slab_base = reinterpret_cast<char*>(a.slabs) + (size_t)tile * nsplit * PB;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab_base, 0, (unsigned)nsplit * PB, 0x00020000);
     const unsigned lane_off = (unsigned)((wave & 3) * 2 * TB * 1024 + lane * 16);
     if (computes) {
 #pragma unroll
@@ -365,22 +374,23 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
           u32x4 v;
           v.x = __float_as_uint(acc[rb][tb][0]); v.y = __float_as_uint(acc[rb][tb][1]);
           v.z = __float_as_uint(acc[rb][tb][2]); v.w = __float_as_uint(acc[rb][tb][3]);
-          __builtin_amdgcn_raw_buffer_store_b128(
-              v, rs, (unsigned)part * PB + lane_off + (unsigned)((rb * TB + tb0 + tb) * 1024), 0, 16);
+          const unsigned off = (unsigned)part * PB + lane_off + (unsigned)((rb * TB + tb0 + tb) * 1024);
+          KX_TOUCH(a, RB_SLABS, slab_base + off, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) *flag = atomicInc(a.tickets + tile, (unsigned)nsplit - 1u) == (unsigned)nsplit - 1u;
+    if (tid == 0) *flag = atomicInc(KX_CK(a, RB_TICKETS, a.tickets + tile), (unsigned)nsplit - 1u) == (unsigned)nsplit - 1u;
     __syncthreads();
     if (!*flag || !computes) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: device-scope loads below
     switch (nsplit) {
-      case 2: rows_combine<2, TB, TBW>(acc, rs, lane_off, tb0); break;
-      case 4: rows_combine<4, TB, TBW>(acc, rs, lane_off, tb0); break;
-      case 8: rows_combine<8, TB, TBW>(acc, rs, lane_off, tb0); break;
-      default: rows_combine<16, TB, TBW>(acc, rs, lane_off, tb0); break;
+      case 2: rows_combine<2, TB, TBW>(a, slab_base, acc, rs, lane_off, tb0); break;
+      case 4: rows_combine<4, TB, TBW>(a, slab_base, acc, rs, lane_off, tb0); break;
+      case 8: rows_combine<8, TB, TBW>(a, slab_base, acc, rs, lane_off, tb0); break;
+      default: rows_combine<16, TB, TBW>(a, slab_base, acc, rs, lane_off, tb0); break;
     }
   }
   if (!computes) return;
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
         const int t = (tb0 + tb) * 16 + 4 * (lane >> 4) + r;
         if (t < a.T) {
           const float g = acc[0][tb][r], u = acc[1][tb][r];
-          a.h16[(size_t)t * a.ldh + row0] = sat_f16(g * (1.0f / (1.0f + expf(-g))) * u);
+          *KX_CK(a, RB_H16, a.h16 + ((size_t)t * a.ldh + row0)) = sat_f16(g * (1.0f / (1.0f + expf(-g))) * u);
         }
       }
     return;
@@ -408,11 +418,12 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
     float* dst;
     int64_t ld;
     int c0;
-    if (row0 < a.k0) { dst = a.y0; ld = a.ld0; c0 = row0; }
-    else if (row0 < a.k1) { dst = a.y1; ld = a.ld1; c0 = row0 - a.k0; }
-    else { dst = a.y2; ld = a.ld2; c0 = row0 - a.k1; }
+    [[maybe_unused]] int op;
+    if (row0 < a.k0) { dst = a.y0; ld = a.ld0; c0 = row0; op = RB_Y0; }
+    else if (row0 < a.k1) { dst = a.y1; ld = a.ld1; c0 = row0 - a.k0; op = RB_Y1; }
+    else { dst = a.y2; ld = a.ld2; c0 = row0 - a.k1; op = RB_Y2; }
     const int c1 = c0 + map.rbstep;
-    const float b0 = a.bias ? a.bias[row0] : 0.f, b1 = a.bias ? a.bias[row1] : 0.f;
+    const float b0 = a.bias ? *KX_CK(a, RB_BIAS, a.bias + row0) : 0.f, b1 = a.bias ? *KX_CK(a, RB_BIAS, a.bias + row1) : 0.f;
     const int in_head = row0 % a.head_size;
     const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
 #pragma unroll
@@ -424,13 +435,13 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
           float o0 = acc[0][tb][r] + b0, o1 = acc[1][tb][r] + b1;
           if (rotate) {
             const size_t ti = (size_t)(a.pos0 + t) * a.head_size + tab;
-            const float fci = a.sin_cache[ti], fcr = a.cos_cache[ti];
+            const float fci = *KX_CK(a, RB_SIN, a.sin_cache + ti), fcr = *KX_CK(a, RB_COS, a.cos_cache + ti);
             const float t0 = o0 * fcr - o1 * fci;
             o1 = o0 * fci + o1 * fcr;
             o0 = t0;
           }
-          dst[(size_t)t * ld + c0] = o0;
-          dst[(size_t)t * ld + c1] = o1;
+          *KX_CK(a, op, dst + ((size_t)t * ld + c0)) = o0;
+          *KX_CK(a, op, dst + ((size_t)t * ld + c1)) = o1;
         }
       }
     return;
@@ -442,13 +453,14 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
     float* dst;
     int64_t ld;
     int col;
+    [[maybe_unused]] int op;
     bool add_res = false;
     if (n < a.k0) {
-      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr;
+      dst = a.y0; ld = a.ld0; col = n; add_res = a.residual != nullptr; op = RB_Y0;
     } else if (n < a.k1) {
-      dst = a.y1; ld = a.ld1; col = n - a.k0;
+      dst = a.y1; ld = a.ld1; col = n - a.k0; op = RB_Y1;
     } else {
-      dst = a.y2; ld = a.ld2; col = n - a.k1;
+      dst = a.y2; ld = a.ld2; col = n - a.k1; op = RB_Y2;
     }
 #pragma unroll
     for (int tb = 0; tb < TBW; ++tb)
@@ -457,8 +469,8 @@ __global__ __launch_bounds__(64 * (4 * PAIR + 1), 1) void gemm_w8_rows_kernel(co
         const int t = (tb0 + tb) * 16 + 4 * (lane >> 4) + r;
         if (t < a.T) {
           float v = acc[rb][tb][r];
-          if (add_res) v += a.residual[(size_t)t * a.ldr + col];
-          dst[(size_t)t * ld + col] = v;
+          if (add_res) v += *KX_CK(a, RB_RES, a.residual + ((size_t)t * a.ldr + col));
+          *KX_CK(a, op, dst + ((size_t)t * ld + col)) = v;
         }
       }
   }
@@ -491,13 +503,13 @@ static int launch_rows(const RowsArgs& a, hipStream_t s) {
 }
 
 __global__ void rows_f32_to_f16_kernel(const float* __restrict__ x, int64_t ldx, _Float16* __restrict__ y,
-                                       int32_t M, int64_t n4) {
+                                       int32_t M, int64_t n4 KX_BPARAM(2)) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / (M / 4), c = (i % (M / 4)) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * ldx + c);
+    const f32x4 v = *KX_CKP(0, reinterpret_cast<const f32x4*>(x + t * ldx + c));
     f16x4 h;
     h[0] = sat_f16(v[0]); h[1] = sat_f16(v[1]); h[2] = sat_f16(v[2]); h[3] = sat_f16(v[3]);
-    *reinterpret_cast<f16x4*>(y + t * M + c) = h;
+    *KX_CKP(1, reinterpret_cast<f16x4*>(y + t * M + c)) = h;
   }
 }
 
@@ -529,7 +541,7 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
     _Float16* x16 = reinterpret_cast<_Float16*>(ws + kRowsTicketBytes);
     const int64_t n4 = (int64_t)T * (M / 4);
     hipLaunchKernelGGL(rows_f32_to_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                       static_cast<const float*>(X), ldx, x16, M, n4);
+                       static_cast<const float*>(X), ldx, x16, M, n4 KX_BPASS(2, X, x16));
     KX_LAUNCH_CHECK();
     X = x16;
     ldx = M;
@@ -557,6 +569,10 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   }
   a.tickets = reinterpret_cast<unsigned*>(ws);
   a.slabs = have_ws ? reinterpret_cast<float*>(ws + kRowsTicketBytes + kRowsX16Bytes) : nullptr;
+  KX_BSET(a, RB_X, a.X); KX_BSET(a, RB_W, a.w); KX_BSET(a, RB_S, a.scales); KX_BSET(a, RB_RES, a.residual);
+  KX_BSET(a, RB_Y0, a.y0); KX_BSET(a, RB_Y1, a.y1); KX_BSET(a, RB_Y2, a.y2); KX_BSET(a, RB_SLABS, a.slabs);
+  KX_BSET(a, RB_TICKETS, a.tickets); KX_BSET(a, RB_H16, a.h16); KX_BSET(a, RB_SIN, a.sin_cache);
+  KX_BSET(a, RB_COS, a.cos_cache); KX_BSET(a, RB_BIAS, a.bias);
   switch (TB) {
     case 1: return launch_rows<1, 1>(a, s);
     case 2: return launch_rows<2, 1>(a, s);

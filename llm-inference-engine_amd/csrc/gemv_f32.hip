@@ -2,6 +2,7 @@
 // Stands in for matmul_kernel_cu_fp32 (kuiper/source/op/kernels/cuda/matmul_kernel.cu:6-54) and
 // matmul_kernel_cpu (cpu/matmul_kernel.cpp:5-41).  One wavefront per row, 128-bit loads
 // (256 floats per wave instruction), x staged once per workgroup in LDS, DPP / permlane-swap reduce.
+#define KX_FILE_ID 8
 #include "kx_common.hpp"
 
 namespace kx {
@@ -9,14 +10,14 @@ namespace kx {
 template <int R, int U>
 __global__ void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                 float* __restrict__ y, int M, int K, float scale, int chunks,
-                                int rows_per_block) {
+                                int rows_per_block KX_BPARAM(3)) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* xs = reinterpret_cast<f32x4*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int m4 = M >> 2;
   for (int i = tid; i < chunks * 64; i += blockDim.x) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < m4) v = reinterpret_cast<const f32x4*>(x)[i];
+    if (i < m4) v = *KX_CKP(0, reinterpret_cast<const f32x4*>(x) + i);
     xs[i] = v;
   }
   __syncthreads();
@@ -37,7 +38,7 @@ __global__ void gemv_f32_kernel(const float* __restrict__ x, const float* __rest
           wv[r][u] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (i4 < m4)
             wv[r][u] = __builtin_nontemporal_load(
-                reinterpret_cast<const f32x4*>(w + (size_t)row * (size_t)M) + i4);
+                KX_CKP(1, reinterpret_cast<const f32x4*>(w + (size_t)row * (size_t)M) + i4));
         }
       }
 #pragma unroll
@@ -57,21 +58,21 @@ __global__ void gemv_f32_kernel(const float* __restrict__ x, const float* __rest
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const float v = wave_sum(total[r]);
-      if (lane == 0 && r0 + r < row_end) y[r0 + r] = v * scale;
+      if (lane == 0 && r0 + r < row_end) *KX_CKP(2, y + (r0 + r)) = v * scale;
     }
   }
 }
 
 // Any M, any alignment: one wave per row, scalar loads.
 __global__ void gemv_f32_generic_kernel(const float* x, const float* w, float* y, int M, int K,
-                                        float scale) {
+                                        float scale KX_BPARAM(3)) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= K) return;
   float total = 0.f;
-  for (int i = lane; i < M; i += 64) total = fmaf(x[i], w[(size_t)row * M + i], total);
+  for (int i = lane; i < M; i += 64) total = fmaf(*KX_CKP(0, x + i), *KX_CKP(1, w + ((size_t)row * M + i)), total);
   total = wave_sum(total);
-  if (lane == 0) y[row] = total * scale;
+  if (lane == 0) *KX_CKP(2, y + row) = total * scale;
 }
 
 }  // namespace kx
@@ -85,7 +86,7 @@ extern "C" int kx_gemv_f32(const float* x, const float* w, float* y, int32_t M, 
                     (size_t)M * 4 <= 64 * 1024;
   if (!fast) {
     hipLaunchKernelGGL(gemv_f32_generic_kernel, dim3((K + 3) / 4), dim3(256), 0, s, x, w, y, M, K,
-                       scale);
+                       scale KX_BPASS(3, x, w, y));
     KX_LAUNCH_CHECK();
     return KX_OK;
   }
@@ -99,7 +100,7 @@ extern "C" int kx_gemv_f32(const float* x, const float* w, float* y, int32_t M, 
   rpb = ((rpb + per_iter - 1) / per_iter) * per_iter;
   const int grid = (K + rpb - 1) / rpb;
   hipLaunchKernelGGL((gemv_f32_kernel<R, U>), dim3(grid), dim3(threads), lds, s, x, w, y, M, K,
-                     scale, chunks, rpb);
+                     scale, chunks, rpb KX_BPASS(3, x, w, y));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

@@ -66,16 +66,19 @@ __device__ __forceinline__ int map_row(const GemvW8Args& a, int v) {
   return v;
 }
 
-__device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, float*& dst, int& r) {
+__device__ __forceinline__ void route(const GemvW8Args& a, int row, int pos, float*& dst, int& r, int& operand) {
   if (row < a.k0) {
     dst = a.y0;
     r = row;
+    operand = GB_Y0;
   } else if (row < a.k1) {
     dst = a.y1 + (size_t)pos * a.kv_pos_stride;
     r = row - a.k0;
+    operand = GB_Y1;
   } else {
     dst = a.y2 + (size_t)pos * a.kv_pos_stride;
     r = row - a.k1;
+    operand = GB_Y2;
   }
 }
 
@@ -85,13 +88,14 @@ __device__ __forceinline__ void store_routed(const GemvW8Args& a, int row, int p
   if (a.kv_f16 && row >= a.k0) {
     const bool is_k = row < a.k1;
     _Float16* dst = reinterpret_cast<_Float16*>(is_k ? a.y1 : a.y2) + (size_t)pos * a.kv_pos_stride;
-    dst[row - (is_k ? a.k0 : a.k1)] = (_Float16)v;
+    *KX_CK(a, is_k ? GB_Y1 : GB_Y2, dst + (row - (is_k ? a.k0 : a.k1))) = (_Float16)v;
     return;
   }
   float* dst;
   int rr;
-  route(a, row, pos, dst, rr);
-  dst[rr] = v;
+  [[maybe_unused]] int op;
+  route(a, row, pos, dst, rr, op);
+  *KX_CK(a, op, dst + rr) = v;
 }
 
 // Issues the 128-bit weight loads (and the one scale per load) of U chunks of R rows.
@@ -115,14 +119,14 @@ __device__ __forceinline__ void load_batch(const GemvW8Args& a, int r0, int c0, 
     for (int r = 0; r < R; ++r) {
       const int row = rows[r];
       const size_t off = (size_t)row * (size_t)a.M + (size_t)col;
-      wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off));
-      sc[r][u] = __builtin_nontemporal_load(a.scales + (size_t)row * a.groups_per_row +
-                                            (col >> a.gs_shift));
+      wv[r][u] = __builtin_nontemporal_load(KX_CK(a, GB_W, reinterpret_cast<const i32x4*>(a.w + off)));
+      sc[r][u] = __builtin_nontemporal_load(KX_CK(a, GB_S, a.scales + (size_t)row * a.groups_per_row +
+                                                               (col >> a.gs_shift)));
       if constexpr (GU) {
         const size_t off2 = off + (size_t)a.swiglu_half * (size_t)a.M;
-        wv2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.w + off2));
-        sc2[r][u] = __builtin_nontemporal_load(
-            a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift));
+        wv2[r][u] = __builtin_nontemporal_load(KX_CK(a, GB_W, reinterpret_cast<const i32x4*>(a.w + off2)));
+        sc2[r][u] = __builtin_nontemporal_load(KX_CK(
+            a, GB_S, a.scales + (size_t)(row + a.swiglu_half) * a.groups_per_row + (col >> a.gs_shift)));
       }
     }
   }
@@ -151,8 +155,8 @@ __device__ __forceinline__ void request_x(const GemvW8Args& a, int i0, GemvXRegs
 #pragma unroll
   for (int j = 0; j < kXPer; ++j) {
     const int idx = min(i0 + j * bd, m4 - 1);
-    X.v[j] = xg[idx];
-    if (a.norm_w) X.g[j] = ng[idx];
+    X.v[j] = *KX_CK(a, GB_X, xg + idx);
+    if (a.norm_w) X.g[j] = *KX_CK(a, GB_NORM, ng + idx);
   }
 }
 
@@ -247,9 +251,9 @@ __device__ __forceinline__ void request_epilogue(const GemvW8Args& a, int r0, in
   for (int r = 0; r < R; ++r) {
     const int row = map_row<MODE>(a, min(r0 + r, row_end - 1));
     float b = 0.f, res = 0.f;
-    if (a.bias) b = a.bias[row];
+    if (a.bias) b = *KX_CK(a, GB_BIAS, a.bias + row);
     if constexpr (MODE != GEMV_QKV_ROPE) {
-      if (a.residual) res = a.residual[row];
+      if (a.residual) res = *KX_CK(a, GB_RES, a.residual + row);
     } else if ((r & 1) == 0) {
       // rope_kernel_cu (cuda/rope_kernel.cu:17-34 half split, :111-127 interleaved).  Only q and k
       // rows are rotated.  A v row keeps its own index inside the head (map_row leaves it alone), so
@@ -257,8 +261,8 @@ __device__ __forceinline__ void request_epilogue(const GemvW8Args& a, int r0, in
       // such rows read entry 0, which nothing uses.
       const int in_head = row < a.k1 ? row % a.head_size : 0;
       const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
-      S.rope_s[r / 2] = a.sin_cache[(size_t)pos * a.head_size + tab];
-      S.rope_c[r / 2] = a.cos_cache[(size_t)pos * a.head_size + tab];
+      S.rope_s[r / 2] = *KX_CK(a, GB_SIN, a.sin_cache + ((size_t)pos * a.head_size + tab));
+      S.rope_c[r / 2] = *KX_CK(a, GB_COS, a.cos_cache + ((size_t)pos * a.head_size + tab));
     }
     S.bias[r] = b;
     S.residual[r] = res;
@@ -328,8 +332,9 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
       if (row < row_end) {
         float* dst;
         int rr;
-        route(a, row, 0, dst, rr);
-        dst[rr] = S.total[r] + (S.bias[r] + S.residual[r]);
+        [[maybe_unused]] int op;
+        route(a, row, 0, dst, rr, op);
+        *KX_CK(a, op, dst + rr) = S.total[r] + (S.bias[r] + S.residual[r]);
       }
     }
   }
@@ -363,7 +368,7 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
   }
   float rs = 1.0f;
   int pos = 0;
-  if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *a.pos_dev : a.pos_val;
+  if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *KX_CK(a, GB_POS, a.pos_dev) : a.pos_val;
 
   GemvBatch<R, U, GU> B;
   GemvRows<R, GU> S;
@@ -423,22 +428,23 @@ __global__ void gemv_w8_generic_kernel(const GemvW8Args a, int32_t group_size) {
   float total = 0.f;
   const size_t base = (size_t)row * (size_t)a.M;
   for (int i = lane * 4; i < a.M; i += 256) {
-    const int32_t wv = *reinterpret_cast<const int32_t*>(a.w + base + i);
+    const int32_t wv = *KX_CK(a, GB_W, reinterpret_cast<const int32_t*>(a.w + base + i));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const size_t idx = base + (size_t)(i + e);
-      const float s = a.scales[idx / (size_t)group_size];
-      total = fmaf(a.x[i + e] * s, (float)(int8_t)(wv >> (8 * e)), total);
+      const float s = *KX_CK(a, GB_S, a.scales + idx / (size_t)group_size);
+      total = fmaf(*KX_CK(a, GB_X, a.x + (i + e)) * s, (float)(int8_t)(wv >> (8 * e)), total);
     }
   }
   total = wave_sum(total);
   if (lane == 0) {
-    if (a.bias) total += a.bias[row];
-    if (a.residual) total += a.residual[row];
+    if (a.bias) total += *KX_CK(a, GB_BIAS, a.bias + row);
+    if (a.residual) total += *KX_CK(a, GB_RES, a.residual + row);
     float* dst;
     int rr;
-    route(a, row, 0, dst, rr);
-    dst[rr] = total;
+    [[maybe_unused]] int op;
+    route(a, row, 0, dst, rr, op);
+    *KX_CK(a, op, dst + rr) = total;
   }
 }
 
@@ -469,6 +475,10 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
   if (a.M <= 0 || a.K <= 0 || group_size <= 0) return KX_EINVAL;
   if (a.M % 4 != 0) return KX_EINVAL;  // matmul_kernel.cu:123
   if (((size_t)a.M * (size_t)a.K) % (size_t)group_size != 0) return KX_EINVAL;
+  KX_BSET(a, GB_X, a.x); KX_BSET(a, GB_W, a.w); KX_BSET(a, GB_S, a.scales);
+  KX_BSET(a, GB_Y0, a.y0); KX_BSET(a, GB_Y1, a.y1); KX_BSET(a, GB_Y2, a.y2);
+  KX_BSET(a, GB_BIAS, a.bias); KX_BSET(a, GB_RES, a.residual); KX_BSET(a, GB_NORM, a.norm_w);
+  KX_BSET(a, GB_SIN, a.sin_cache); KX_BSET(a, GB_COS, a.cos_cache); KX_BSET(a, GB_POS, a.pos_dev);
   const bool pow2 = (group_size & (group_size - 1)) == 0;
   const bool fast = pow2 && group_size % 16 == 0 && a.M % group_size == 0 && a.M % 16 == 0 &&
                     ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&

@@ -1,5 +1,8 @@
 // Argument block and dispatcher shared by the W8 GEMV entry points.
 #pragma once
+#ifndef KX_FILE_ID
+#define KX_FILE_ID 1
+#endif
 #include "kx_common.hpp"
 
 namespace kx {
@@ -33,7 +36,9 @@ struct GemvW8Args {
   int32_t head_size;
   int32_t kv_pos_stride;  // y1/y2 are advanced by pos * kv_pos_stride elements (KV-cache row)
   int32_t kv_f16;         // GEMV_QKV_ROPE: y1/y2 point at fp16 cache rows
+  KX_BFIELD(12)  // operands of the bounds-checking build, in the order of GemvOperand
 };
+enum GemvOperand { GB_X, GB_W, GB_S, GB_Y0, GB_Y1, GB_Y2, GB_BIAS, GB_RES, GB_NORM, GB_SIN, GB_COS, GB_POS };
 
 int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s);
 

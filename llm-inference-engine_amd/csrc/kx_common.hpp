@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <initializer_list>
+
 #include "../../include/kx_hip.h"
 
 // fp32 -> fp16 with saturation: a value past the fp16 range becomes +-65504 instead of an
@@ -36,6 +38,98 @@ struct OncePerDevice {
     hipError_t e_ = hipGetLastError();          \
     if (e_ != hipSuccess) return (int)e_;       \
   } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Bounds-checking build (make BOUNDS=1, -DKX_BOUNDS).  A read a few bytes past an array cannot be
+// seen by a parity test (nothing uses the value) and faults the device only when the array ends on
+// the last mapped page.  In this build every kernel's argument block carries, per operand, the
+// byte range of the ALLOCATION the operand points into (resolved on the host, at launch, from the
+// library's own table of kx_malloc blocks), and every global load / store / LDS-DMA address is
+// compared with its operand's range first.  A violation never traps: the access is redirected to
+// the first byte of the range and {site, operand, offset, extent} goes into a device record that
+// kx_bounds_report() reads back.  In the normal build every macro below expands to its pointer
+// argument and the argument blocks are unchanged.
+//   KX_BFIELD(N)              member of an argument struct: N operand ranges
+//   KX_BSET(a, i, ptr)        host, before the launch: operand i of `a` is the block holding ptr
+//   KX_CK(a, i, ptr)          device: ptr (of operand i), checked for sizeof(*ptr) bytes
+//   KX_CKN(a, i, ptr, bytes)  the same for an access of `bytes` bytes
+//   KX_TOUCH(a, i, ptr, bytes) check and record only (buffer instructions, whose descriptor already
+//                             keeps the hardware inside its range)
+// Kernels that take plain pointer parameters instead of a struct: KX_BPARAM(N) as the last
+// parameter, KX_BPASS(N, ...pointers) as the last launch argument, KX_CKP / KX_CKPN in the body
+// (KX_BFWD hands the ranges on to a device function declared with KX_BPARAM).
+#ifndef KX_FILE_ID
+#define KX_FILE_ID 0
+#endif
+#define KX_SITE ((unsigned)((KX_FILE_ID << 16) | __LINE__))
+#ifdef KX_BOUNDS
+namespace kx {
+struct BRange { const char* lo; const char* hi; };  // hi == nullptr: memory the table does not know
+struct BoundsEntry { unsigned site, operand; long long offset, extent; };
+struct BoundsLog { unsigned long long total; BoundsEntry e[1024]; };
+template <int N>
+struct BArgs { BRange r[N]; BoundsLog* log; };
+
+// host side (runtime.hip)
+BRange bounds_lookup(const void* p);
+BoundsLog* bounds_log();
+void bounds_track(const void* p, size_t bytes);
+void bounds_untrack(const void* p);
+template <int N>
+inline void bounds_set(BArgs<N>& b, int i, const void* p) {
+  b.r[i] = p ? bounds_lookup(p) : BRange{nullptr, nullptr};
+  b.log = bounds_log();
+}
+template <int N>
+inline BArgs<N> bounds_make(std::initializer_list<const void*> ps) {
+  BArgs<N> b{};
+  int i = 0;
+  for (const void* p : ps) bounds_set(b, i++, p);
+  b.log = bounds_log();
+  return b;
+}
+
+__device__ __noinline__ static void bounds_note(BoundsLog* log, unsigned site, unsigned operand,
+                                                long long offset, long long extent) {
+  if (!log) return;
+  const unsigned long long n = atomicAdd(&log->total, 1ull);
+  if (n < 1024) log->e[n] = BoundsEntry{site, operand, offset, extent};
+}
+template <int N, class T>
+__device__ __forceinline__ T* bounds_ck(const BArgs<N>& b, int i, unsigned site, T* p, size_t bytes) {
+  const BRange r = b.r[i];
+  const char* c = reinterpret_cast<const char*>(p);
+  if (r.hi && (c < r.lo || c + bytes > r.hi)) {
+    bounds_note(b.log, site, (unsigned)i, (long long)(c - r.lo), (long long)(r.hi - r.lo));
+    return reinterpret_cast<T*>(const_cast<char*>(r.lo));
+  }
+  return p;
+}
+}  // namespace kx
+#define KX_BFIELD(N) kx::BArgs<N> kxb;
+#define KX_BSET(a, i, ptr) kx::bounds_set((a).kxb, (i), (ptr))
+#define KX_CK(a, i, ptr) kx::bounds_ck((a).kxb, (i), KX_SITE, (ptr), sizeof(*(ptr)))
+#define KX_CKN(a, i, ptr, bytes) kx::bounds_ck((a).kxb, (i), KX_SITE, (ptr), (size_t)(bytes))
+#define KX_TOUCH(a, i, ptr, bytes) ((void)kx::bounds_ck((a).kxb, (i), KX_SITE, (ptr), (size_t)(bytes)))
+#define KX_BPARAM(N) , const kx::BArgs<N> kxb
+#define KX_BPASS(N, ...) , kx::bounds_make<N>({__VA_ARGS__})
+#define KX_BFWD , kxb
+#define KX_TOUCHP(i, ptr, bytes) ((void)kx::bounds_ck(kxb, (i), KX_SITE, (ptr), (size_t)(bytes)))
+#define KX_CKP(i, ptr) kx::bounds_ck(kxb, (i), KX_SITE, (ptr), sizeof(*(ptr)))
+#define KX_CKPN(i, ptr, bytes) kx::bounds_ck(kxb, (i), KX_SITE, (ptr), (size_t)(bytes))
+#else
+#define KX_BFIELD(N)
+#define KX_BSET(a, i, ptr) ((void)0)
+#define KX_CK(a, i, ptr) (ptr)
+#define KX_CKN(a, i, ptr, bytes) (ptr)
+#define KX_TOUCH(a, i, ptr, bytes) ((void)0)
+#define KX_BPARAM(N)
+#define KX_BPASS(N, ...)
+#define KX_BFWD
+#define KX_TOUCHP(i, ptr, bytes) ((void)0)
+#define KX_CKP(i, ptr) (ptr)
+#define KX_CKPN(i, ptr, bytes) (ptr)
+#endif
 
 namespace kx {
 

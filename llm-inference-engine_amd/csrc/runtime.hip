@@ -4,7 +4,91 @@
 // (kuiper/include/base/cuda_config.h:6-17).  No pooling: the token path allocates once.
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "kx_common.hpp"
+
+// ---- bounds-checking build: the table of live kx_malloc blocks and the violation record ----
+#ifdef KX_BOUNDS
+namespace kx {
+namespace {
+std::mutex g_bmu;
+std::map<uintptr_t, size_t> g_blocks;  // base -> bytes
+BoundsLog* g_blog = nullptr;
+}  // namespace
+void bounds_track(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_bmu);
+  g_blocks[(uintptr_t)p] = bytes;
+}
+void bounds_untrack(const void* p) {
+  std::lock_guard<std::mutex> lk(g_bmu);
+  g_blocks.erase((uintptr_t)p);
+}
+BRange bounds_lookup(const void* p) {
+  std::lock_guard<std::mutex> lk(g_bmu);
+  auto it = g_blocks.upper_bound((uintptr_t)p);
+  if (it == g_blocks.begin()) return BRange{nullptr, nullptr};
+  --it;
+  if ((uintptr_t)p >= it->first + it->second) return BRange{nullptr, nullptr};  // not one of ours
+  return BRange{reinterpret_cast<const char*>(it->first), reinterpret_cast<const char*>(it->first + it->second)};
+}
+BoundsLog* bounds_log() {
+  std::lock_guard<std::mutex> lk(g_bmu);
+  if (!g_blog) {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(BoundsLog)) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, sizeof(BoundsLog));
+    g_blog = static_cast<BoundsLog*>(p);
+  }
+  return g_blog;
+}
+}  // namespace kx
+#endif
+
+extern "C" int kx_bounds_enabled(void) {
+#ifdef KX_BOUNDS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+extern "C" int kx_bounds_report(kx_bounds_record* out, int32_t max_records, uint64_t* total) {
+  if (total) *total = 0;
+#ifdef KX_BOUNDS
+  kx::BoundsLog* log = kx::bounds_log();
+  if (!log) return KX_EINVAL;
+  KX_HIP_TRY(hipDeviceSynchronize());
+  static kx::BoundsLog host;
+  KX_HIP_TRY(hipMemcpy(&host, log, sizeof(host), hipMemcpyDeviceToHost));
+  if (total) *total = host.total;
+  const uint64_t n = host.total < 1024 ? host.total : 1024;
+  for (uint64_t i = 0; i < n && out && (int64_t)i < max_records; ++i) {
+    out[i].file_id = (int32_t)(host.e[i].site >> 16);
+    out[i].line = (int32_t)(host.e[i].site & 0xffff);
+    out[i].operand = (int32_t)host.e[i].operand;
+    out[i].offset = host.e[i].offset;
+    out[i].extent = host.e[i].extent;
+  }
+  return KX_OK;
+#else
+  (void)out; (void)max_records;
+  return KX_EUNSUPPORTED;
+#endif
+}
+
+extern "C" int kx_bounds_reset(void) {
+#ifdef KX_BOUNDS
+  kx::BoundsLog* log = kx::bounds_log();
+  if (!log) return KX_EINVAL;
+  KX_HIP_TRY(hipDeviceSynchronize());
+  KX_HIP_TRY(hipMemset(log, 0, sizeof(kx::BoundsLog)));
+  return KX_OK;
+#else
+  return KX_EUNSUPPORTED;
+#endif
+}
 
 extern "C" const char* kx_error_string(int code) {
   switch (code) {
@@ -50,10 +134,16 @@ extern "C" int kx_malloc(void** ptr, size_t bytes) {
   *ptr = nullptr;
   if (bytes == 0) return KX_OK;
   KX_HIP_TRY(hipMalloc(ptr, bytes));
+#ifdef KX_BOUNDS
+  kx::bounds_track(*ptr, bytes);
+#endif
   return KX_OK;
 }
 extern "C" int kx_free(void* ptr) {
   if (!ptr) return KX_OK;
+#ifdef KX_BOUNDS
+  kx::bounds_untrack(ptr);
+#endif
   KX_HIP_TRY(hipFree(ptr));
   return KX_OK;
 }

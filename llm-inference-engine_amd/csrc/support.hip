@@ -1,6 +1,7 @@
 // Support kernels of the token path: RMSNorm, RoPE (+ table), SwiGLU, add, embedding gather,
 // greedy argmax.  Each is O(dim) bytes per token next to O(dim^2) weight bytes, so they are kept
 // simple, vectorised and correct; the reference twins are cited per kernel.
+#define KX_FILE_ID 7
 #include "kx_common.hpp"
 
 namespace kx {
@@ -19,31 +20,31 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // The same normalisation with the result rounded to fp16 (activations of the prefill GEMMs).
 __global__ void rmsnorm_f16out_kernel(const float* __restrict__ in, const float* __restrict__ weight,
-                                      _Float16* __restrict__ out, int dim, float eps) {
+                                      _Float16* __restrict__ out, int dim, float eps KX_BPARAM(3)) {
   __shared__ float red[16];
   const f32x4* x4 = reinterpret_cast<const f32x4*>(in + (size_t)blockIdx.x * dim);
   const f32x4* w4 = reinterpret_cast<const f32x4*>(weight);
   f16x4* o4 = reinterpret_cast<f16x4*>(out + (size_t)blockIdx.x * dim);
   float ss = 0.f;
   for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
-    const f32x4 v = x4[i];
+    const f32x4 v = *KX_CKP(0, x4 + i);
     ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
   ss = block_sum(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)dim + eps);
   for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
-    const f32x4 v = x4[i], w = w4[i];
+    const f32x4 v = *KX_CKP(0, x4 + i), w = *KX_CKP(1, w4 + i);
     f16x4 h;
     h[0] = sat_f16(w.x * (rs * v.x)); h[1] = sat_f16(w.y * (rs * v.y));
     h[2] = sat_f16(w.z * (rs * v.z)); h[3] = sat_f16(w.w * (rs * v.w));
-    o4[i] = h;
+    *KX_CKP(2, o4 + i) = h;
   }
 }
 
 // row_rmsnorm_f32 (kuiper/source/op/kernels/cuda/rmsnorm_kernel.cu:62-108):
 // out = weight * (x * rsqrt(mean(x^2) + eps)); one workgroup per row.
 __global__ void rmsnorm_kernel(const float* __restrict__ in, const float* __restrict__ weight,
-                               float* __restrict__ out, int dim, float eps) {
+                               float* __restrict__ out, int dim, float eps KX_BPARAM(3)) {
   __shared__ float red[16];
   const float* x = in + (size_t)blockIdx.x * dim;
   float* o = out + (size_t)blockIdx.x * dim;
@@ -53,11 +54,11 @@ __global__ void rmsnorm_kernel(const float* __restrict__ in, const float* __rest
   if (vec) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
-      const f32x4 v = x4[i];
+      const f32x4 v = *KX_CKP(0, x4 + i);
       ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
   } else {
-    for (int i = threadIdx.x; i < dim; i += blockDim.x) ss += x[i] * x[i];
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) ss += *KX_CKP(0, x + i) * x[i];
   }
   ss = block_sum(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)dim + eps);
@@ -66,24 +67,24 @@ __global__ void rmsnorm_kernel(const float* __restrict__ in, const float* __rest
     const f32x4* w4 = reinterpret_cast<const f32x4*>(weight);
     f32x4* o4 = reinterpret_cast<f32x4*>(o);
     for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) {
-      const f32x4 v = x4[i], w = w4[i];
-      o4[i] = f32x4{w.x * (rs * v.x), w.y * (rs * v.y), w.z * (rs * v.z), w.w * (rs * v.w)};
+      const f32x4 v = *KX_CKP(0, x4 + i), w = *KX_CKP(1, w4 + i);
+      *KX_CKP(2, o4 + i) = f32x4{w.x * (rs * v.x), w.y * (rs * v.y), w.z * (rs * v.z), w.w * (rs * v.w)};
     }
   } else {
-    for (int i = threadIdx.x; i < dim; i += blockDim.x) o[i] = weight[i] * (rs * x[i]);
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) *KX_CKP(2, o + i) = *KX_CKP(1, weight + i) * (rs * x[i]);
   }
 }
 
 // sin_cos_calc (cuda/rope_kernel.cu:38-49): table[pos][head_dim], freq = theta^(-head_dim/hs).
 __global__ void sin_cos_kernel(int head_size, int max_seq_len, float theta, float* sin_cache,
-                               float* cos_cache) {
+                               float* cos_cache KX_BPARAM(2)) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= head_size * max_seq_len) return;
   const int pos = idx / head_size, hd = idx % head_size;
   const float freq = 1.0f / powf(theta, (float)hd / (float)head_size);
   const float val = (float)pos * freq;
-  sin_cache[idx] = sinf(val);
-  cos_cache[idx] = cosf(val);
+  *KX_CKP(0, sin_cache + idx) = sinf(val);
+  *KX_CKP(1, cos_cache + idx) = cosf(val);
 }
 
 // rope_kernel_cu_fp32 (cuda/rope_kernel.cu:5-36 half-split, :98-128 interleaved).
@@ -101,7 +102,7 @@ struct RopeBias {
 template <int VARIANT>
 __global__ void rope_kernel(int dim, int kv_dim, int head_size, float* q, float* k, int k_stride,
                             int pos, int rows, const float* __restrict__ sin_cache,
-                            const float* __restrict__ cos_cache, const RopeBias b) {
+                            const float* __restrict__ cos_cache, const RopeBias b KX_BPARAM(8)) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = blockIdx.y;
   if (pair >= dim / 2 || row >= rows) return;
@@ -118,89 +119,89 @@ __global__ void rope_kernel(int dim, int kv_dim, int head_size, float* q, float*
     i1 = i0 + half;
     tab = hd * 2;
   }
-  const float fci = sin_cache[(size_t)p * head_size + tab];
-  const float fcr = cos_cache[(size_t)p * head_size + tab];
+  const float fci = *KX_CKP(2, sin_cache + ((size_t)p * head_size + tab));
+  const float fcr = *KX_CKP(3, cos_cache + ((size_t)p * head_size + tab));
   float* qr = q + (size_t)row * dim;
-  float q0 = qr[i0], q1 = qr[i1];
+  float q0 = *KX_CKP(0, qr + i0), q1 = *KX_CKP(0, qr + i1);
   if (b.bq) {
-    q0 += b.bq[i0];
-    q1 += b.bq[i1];
+    q0 += *KX_CKP(4, b.bq + i0);
+    q1 += *KX_CKP(4, b.bq + i1);
   }
   qr[i0] = q0 * fcr - q1 * fci;
   qr[i1] = q0 * fci + q1 * fcr;
   const int head_base = VARIANT == KX_ROPE_INTERLEAVED ? i0 : (i0 / head_size) * head_size;
   if (head_base < kv_dim) {
     float* kr = k + (size_t)row * k_stride;
-    float k0 = kr[i0], k1 = kr[i1];
+    float k0 = *KX_CKP(1, kr + i0), k1 = *KX_CKP(1, kr + i1);
     if (b.bk) {
-      k0 += b.bk[i0];
-      k1 += b.bk[i1];
+      k0 += *KX_CKP(5, b.bk + i0);
+      k1 += *KX_CKP(5, b.bk + i1);
     }
     kr[i0] = k0 * fcr - k1 * fci;
     kr[i1] = k0 * fci + k1 * fcr;
     if (b.bv) {
       float* vr = b.v + (size_t)row * b.v_stride;
-      vr[i0] += b.bv[i0];
-      vr[i1] += b.bv[i1];
+      *KX_CKP(7, vr + i0) += *KX_CKP(6, b.bv + i0);
+      *KX_CKP(7, vr + i1) += *KX_CKP(6, b.bv + i1);
     }
   }
 }
 
 // swiglu_kernel_cu_fp32 (cuda/swiglu_kernel.cu:4-22)
 __global__ void swiglu_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                              float* __restrict__ out, int n) {
+                              float* __restrict__ out, int n KX_BPARAM(3)) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float g = a[i];
-  out[i] = g * (1.0f / (1.0f + expf(-g))) * b[i];
+  const float g = *KX_CKP(0, a + i);
+  *KX_CKP(2, out + i) = g * (1.0f / (1.0f + expf(-g))) * *KX_CKP(1, b + i);
 }
 
 // Row-batched SwiGLU over a stacked [gate | up] activation: out[t][h] = silu(in[t][h]) *
 // in[t][half + h] (the prefill form of swiglu_kernel_cu_fp32).
 template <typename OutT>
 __global__ void swiglu_rows_kernel(const float* __restrict__ in, int64_t ld_in, int half,
-                                   OutT* __restrict__ out, int64_t ld_out, int rows) {
+                                   OutT* __restrict__ out, int64_t ld_out, int rows KX_BPARAM(2)) {
   const int64_t n4 = (int64_t)rows * (half / 4);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / (half / 4);
     const int h = (int)(i - t * (half / 4)) * 4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(in + t * ld_in + h);
-    const f32x4 u = *reinterpret_cast<const f32x4*>(in + t * ld_in + half + h);
+    const f32x4 g = *KX_CKP(0, reinterpret_cast<const f32x4*>(in + t * ld_in + h));
+    const f32x4 u = *KX_CKP(0, reinterpret_cast<const f32x4*>(in + t * ld_in + half + h));
     f32x4 o;
     o.x = g.x * (1.0f / (1.0f + expf(-g.x))) * u.x;
     o.y = g.y * (1.0f / (1.0f + expf(-g.y))) * u.y;
     o.z = g.z * (1.0f / (1.0f + expf(-g.z))) * u.z;
     o.w = g.w * (1.0f / (1.0f + expf(-g.w))) * u.w;
     if constexpr (sizeof(OutT) == 4) {
-      *reinterpret_cast<f32x4*>(out + t * ld_out + h) = o;
+      *KX_CKP(1, reinterpret_cast<f32x4*>(out + t * ld_out + h)) = o;
     } else {
       f16x4 o16;
       o16[0] = sat_f16(o.x); o16[1] = sat_f16(o.y); o16[2] = sat_f16(o.z); o16[3] = sat_f16(o.w);
-      *reinterpret_cast<f16x4*>(out + t * ld_out + h) = o16;
+      *KX_CKP(1, reinterpret_cast<f16x4*>(out + t * ld_out + h)) = o16;
     }
   }
 }
 
 // add_kernel_cu_fp32 (cuda/add_kernel.cu:4-12)
-__global__ void add_kernel(const float* a, const float* b, float* out, int n) {
+__global__ void add_kernel(const float* a, const float* b, float* out, int n KX_BPARAM(3)) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = a[i] + b[i];
+  if (i < n) *KX_CKP(2, out + i) = *KX_CKP(0, a + i) + *KX_CKP(1, b + i);
 }
 
 // emb_kernel_cu_fp32 (cuda/emb_kernel.cu:3-21): one workgroup per token row.
 __global__ void embedding_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
-                                 float* __restrict__ out, int dim, int vocab) {
+                                 float* __restrict__ out, int dim, int vocab KX_BPARAM(3)) {
   const int t = blockIdx.x;
-  int tok = tokens[t];
+  int tok = *KX_CKP(0, tokens + t);
   if (tok < 0 || tok >= vocab) tok = 0;  // the reference aborts on an out-of-range id
   const float* src = table + (size_t)tok * dim;
   float* dst = out + (size_t)t * dim;
   if (dim % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0)) {
     for (int i = threadIdx.x; i < dim / 4; i += blockDim.x)
-      reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+      *KX_CKP(2, reinterpret_cast<f32x4*>(dst) + i) = *KX_CKP(1, reinterpret_cast<const f32x4*>(src) + i);
   } else {
-    for (int i = threadIdx.x; i < dim; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) *KX_CKP(2, dst + i) = *KX_CKP(1, src + i);
   }
 }
 
@@ -208,16 +209,16 @@ __global__ void embedding_kernel(const int32_t* __restrict__ tokens, const float
 __global__ void embedding_dpos_kernel(const int32_t* __restrict__ history,
                                       const int32_t* __restrict__ pos,
                                       const float* __restrict__ table, float* __restrict__ out,
-                                      int dim, int vocab) {
-  int tok = history[*pos];
+                                      int dim, int vocab KX_BPARAM(4)) {
+  int tok = *KX_CKP(0, history + *KX_CKP(1, pos));
   if (tok < 0 || tok >= vocab) tok = 0;
   const float* src = table + (size_t)tok * dim;
   if (dim % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim / 4; i += gridDim.x * blockDim.x)
-      reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(src)[i];
+      *KX_CKP(3, reinterpret_cast<f32x4*>(out) + i) = *KX_CKP(2, reinterpret_cast<const f32x4*>(src) + i);
   } else {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x)
-      out[i] = src[i];
+      *KX_CKP(3, out + i) = *KX_CKP(2, src + i);
   }
 }
 
@@ -228,13 +229,13 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
     i = oi;
   }
 }
-__global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out) {
+__global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out KX_BPARAM(2)) {
   __shared__ float sv[16];
   __shared__ int si[16];
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = x[i];
+    const float v = *KX_CKP(0, x + i);
     if (v > best) {  // strictly greater: the lowest index of a thread's stripe wins ties
       best = v;
       bi = i;
@@ -254,7 +255,7 @@ __global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out) 
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
-    *out = bi == 0x7fffffff ? 0 : bi;
+    *KX_CKP(1, out) = bi == 0x7fffffff ? 0 : bi;
   }
 }
 
@@ -294,17 +295,20 @@ struct StepArgs {
   int index_base; float* cand;                    // candidate form: {value, global index} and no bookkeeping
   int32_t* token; int32_t* pos; int32_t* history; int history_len; int write_history;
   const float* table; int dim; int vocab; float* x_out;
+  KX_BFIELD(10)  // operands of the bounds-checking build, in the order of StepOperand
 };
+enum StepOperand { SB_LOGITS, SB_PV, SB_PI, SB_TICKET, SB_CAND, SB_TOKEN, SB_POS, SB_HISTORY, SB_TABLE, SB_XOUT };
 
 __device__ __forceinline__ void step_bookkeeping(const StepArgs& a, int bi, int* sm_tok) {
   // thread 0 only
   if (bi == 0x7fffffff) bi = 0;
-  const int p = *a.pos;
-  if (a.history && a.write_history && p + 1 < a.history_len) a.history[p + 1] = bi;
-  *a.token = bi;
+  const int p = *KX_CK(a, SB_POS, a.pos);
+  if (a.history && a.write_history && p + 1 < a.history_len) *KX_CK(a, SB_HISTORY, a.history + (p + 1)) = bi;
+  *KX_CK(a, SB_TOKEN, a.token) = bi;
   *a.pos = p + 1;
   int nxt = -1;
-  if (a.table && a.x_out && a.history && p + 1 < a.history_len) nxt = a.write_history ? bi : a.history[p + 1];
+  if (a.table && a.x_out && a.history && p + 1 < a.history_len)
+    nxt = a.write_history ? bi : *KX_CK(a, SB_HISTORY, a.history + (p + 1));
   *sm_tok = nxt;
 }
 
@@ -315,9 +319,9 @@ __device__ __forceinline__ void step_embed(const StepArgs& a, int tok) {
   const float* src = a.table + (size_t)tok * a.dim;
   if (a.dim % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)a.x_out % 16 == 0)) {
     for (int i = threadIdx.x; i < a.dim / 4; i += blockDim.x)
-      reinterpret_cast<f32x4*>(a.x_out)[i] = reinterpret_cast<const f32x4*>(src)[i];
+      *KX_CK(a, SB_XOUT, reinterpret_cast<f32x4*>(a.x_out) + i) = *KX_CK(a, SB_TABLE, reinterpret_cast<const f32x4*>(src) + i);
   } else {
-    for (int i = threadIdx.x; i < a.dim; i += blockDim.x) a.x_out[i] = src[i];
+    for (int i = threadIdx.x; i < a.dim; i += blockDim.x) *KX_CK(a, SB_XOUT, a.x_out + i) = *KX_CK(a, SB_TABLE, src + i);
   }
 }
 
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256) void step_pick_kernel(const StepArgs a) {
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float v = a.logits[i];
+    const float v = *KX_CK(a, SB_LOGITS, a.logits + i);
     if (v > best) {  // strictly greater: the lowest index of a thread's stripe wins ties
       best = v;
       bi = i;
@@ -339,10 +343,10 @@ __global__ __launch_bounds__(256) void step_pick_kernel(const StepArgs a) {
   block_argmax(best, bi, sv, si);
   if (gridDim.x > 1) {
     if (threadIdx.x == 0) {
-      __hip_atomic_store(a.pv + blockIdx.x, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.pi + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(KX_CK(a, SB_PV, a.pv + blockIdx.x), best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(KX_CK(a, SB_PI, a.pi + blockIdx.x), bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both stores acknowledged before the ticket
-      sm_last = atomicInc(a.ticket, gridDim.x - 1u) == gridDim.x - 1u;
+      sm_last = atomicInc(KX_CK(a, SB_TICKET, a.ticket), gridDim.x - 1u) == gridDim.x - 1u;
     }
     __syncthreads();
     if (!sm_last) return;
@@ -350,15 +354,15 @@ __global__ __launch_bounds__(256) void step_pick_kernel(const StepArgs a) {
     best = -INFINITY;
     bi = 0x7fffffff;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
-      argmax_merge(best, bi, __hip_atomic_load(a.pv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                   __hip_atomic_load(a.pi + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      argmax_merge(best, bi, __hip_atomic_load(KX_CK(a, SB_PV, a.pv + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(KX_CK(a, SB_PI, a.pi + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     __syncthreads();  // sv / si are reused
     block_argmax(best, bi, sv, si);
   }
   if (a.cand) {
     if (threadIdx.x == 0) {
-      a.cand[0] = best;
-      a.cand[1] = bi == 0x7fffffff ? -1.0f : (float)(a.index_base + bi);
+      *KX_CK(a, SB_CAND, a.cand) = best;
+      *KX_CK(a, SB_CAND, a.cand + 1) = bi == 0x7fffffff ? -1.0f : (float)(a.index_base + bi);
     }
     return;
   }
@@ -372,14 +376,14 @@ __global__ __launch_bounds__(256) void step_pick_kernel(const StepArgs a) {
 // `cand`), the candidates are all-gathered, and every rank picks the same winner (largest value,
 // lowest index on ties: the first maximum of the unsharded vector, argmax_sampler.cpp:6-8).
 __global__ __launch_bounds__(256) void step_end_candidates_kernel(const float* __restrict__ cands,
-                                                                  int ranks, const StepArgs a) {
+                                                                  int ranks, const StepArgs a KX_BPARAM(1)) {
   __shared__ int sm_tok;
   if (threadIdx.x == 0) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int r = 0; r < ranks; ++r) {
-      const float idx = cands[2 * r + 1];
-      if (idx >= 0.f) argmax_merge(best, bi, cands[2 * r], (int)idx);
+      const float idx = *KX_CKP(0, cands + (2 * r + 1));
+      if (idx >= 0.f) argmax_merge(best, bi, *KX_CKP(0, cands + 2 * r), (int)idx);
     }
     step_bookkeeping(a, bi, &sm_tok);
   }
@@ -389,9 +393,9 @@ __global__ __launch_bounds__(256) void step_end_candidates_kernel(const float* _
 
 // ---- the pieces the reference's CPU attention is assembled from (cpu/mha_kernel.cpp:19-60) ----
 // scale_inplace_cpu (cpu/scale_kernel.cpp:3-8): x *= scale.
-__global__ void scale_kernel(float scale, float* x, int n) {
+__global__ void scale_kernel(float scale, float* x, int n KX_BPARAM(1)) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= scale;
+  if (i < n) *KX_CKP(0, x + i) *= scale;
 }
 
 __device__ __forceinline__ float block_max(float v, float* red) {
@@ -406,10 +410,10 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // softmax_inplace_cpu (cpu/softmax_kernel.cpp:4-15): x = exp(x - max(x)) / sum; one workgroup.
-__global__ void softmax_kernel(float* x, int n) {
+__global__ void softmax_kernel(float* x, int n KX_BPARAM(1)) {
   __shared__ float red[16];
   float mx = -INFINITY;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, x[i]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, *KX_CKP(0, x + i));
   mx = block_max(mx, red);
   float sum = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -424,11 +428,11 @@ __global__ void softmax_kernel(float* x, int n) {
 // scale_sum_kernel_cpu (cpu/scale_sum_kernel.cpp:5-22): out[d] += sum_{i<=pos} scale[i] *
 // value[i*stride + d], d < size; the terms are added in order of i, one thread per d.
 __global__ void scale_sum_kernel(const float* __restrict__ value, const float* __restrict__ scale,
-                                 float* out, int pos, int size, int stride) {
+                                 float* out, int pos, int size, int stride KX_BPARAM(3)) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= size) return;
-  float acc = out[d];
-  for (int i = 0; i <= pos; ++i) acc = fmaf(scale[i], value[(size_t)i * stride + d], acc);
+  float acc = *KX_CKP(2, out + d);
+  for (int i = 0; i <= pos; ++i) acc = fmaf(*KX_CKP(1, scale + i), *KX_CKP(0, value + ((size_t)i * stride + d)), acc);
   out[d] = acc;
 }
 
@@ -436,18 +440,18 @@ __global__ void scale_sum_kernel(const float* __restrict__ value, const float* _
 // scale = max|w| / 127, q = round_half_even(w / scale); one 64-lane wave per group.  IEEE division
 // and rintf, so the bytes equal the exporter's; an all-zero group gives scale 0 and zeros.
 __global__ void quantize_q80_kernel(const float* __restrict__ w, size_t groups, int gs,
-                                    int8_t* __restrict__ q, float* __restrict__ scales) {
+                                    int8_t* __restrict__ q, float* __restrict__ scales KX_BPARAM(3)) {
   const int lane = threadIdx.x & 63;
   const size_t g = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (g >= groups) return;
   const float* wg = w + g * (size_t)gs;
   float wmax = 0.f;
-  for (int i = lane; i < gs; i += 64) wmax = fmaxf(wmax, fabsf(wg[i]));
+  for (int i = lane; i < gs; i += 64) wmax = fmaxf(wmax, fabsf(*KX_CKP(0, wg + i)));
   wmax = wave_max(wmax);
   const float scale = __fdiv_rn(wmax, 127.0f);
-  if (lane == 0) scales[g] = scale;
+  if (lane == 0) *KX_CKP(2, scales + g) = scale;
   for (int i = lane; i < gs; i += 64)
-    q[g * (size_t)gs + i] = scale > 0.f ? (int8_t)rintf(__fdiv_rn(wg[i], scale)) : (int8_t)0;
+    *KX_CKP(1, q + (g * (size_t)gs + i)) = scale > 0.f ? (int8_t)rintf(__fdiv_rn(wg[i], scale)) : (int8_t)0;
 }
 
 // ---- seeded synthetic tensors, generated on the device ----
@@ -460,24 +464,24 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 __global__ void fill_hash_i8_kernel(int8_t* dst, int rows, int cols, int64_t ld, int64_t row0,
-                                    int64_t col0, uint64_t seed) {
+                                    int64_t col0, uint64_t seed KX_BPARAM(1)) {
   const int64_t n = (int64_t)rows * cols;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / cols, j = t - i * cols;
     const uint64_t h = mix64(seed ^ (uint64_t)((row0 + i) * ld + col0 + j) * 0xD1342543DE82EF95ull);
-    dst[t] = (int8_t)((int)(h % 255ull) - 127);
+    *KX_CKP(0, dst + t) = (int8_t)((int)(h % 255ull) - 127);
   }
 }
 __global__ void fill_hash_f32_kernel(float* dst, int rows, int cols, int64_t ld, int64_t row0,
-                                     int64_t col0, uint64_t seed, float lo, float hi) {
+                                     int64_t col0, uint64_t seed, float lo, float hi KX_BPARAM(1)) {
   const int64_t n = (int64_t)rows * cols;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / cols, j = t - i * cols;
     const uint64_t h = mix64(seed ^ (uint64_t)((row0 + i) * ld + col0 + j) * 0xD1342543DE82EF95ull);
     const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
-    dst[t] = lo + (hi - lo) * u;
+    *KX_CKP(0, dst + t) = lo + (hi - lo) * u;
   }
 }
 
@@ -490,7 +494,7 @@ extern "C" int kx_rmsnorm_f32(const float* in, const float* weight, float* out, 
   if (!in || !weight || !out || dim <= 0 || rows <= 0) return KX_EINVAL;
   const int threads = dim >= 4096 ? 512 : 256;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(threads), 0, (hipStream_t)stream, in, weight,
-                     out, dim, eps);
+                     out, dim, eps KX_BPASS(3, in, weight, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -501,7 +505,7 @@ extern "C" int kx_rmsnorm_f16out(const float* in, const float* weight, void* out
   if (dim % 4 || ((uintptr_t)in | (uintptr_t)weight) % 16 || (uintptr_t)out16 % 8) return KX_EINVAL;
   const int threads = dim >= 4096 ? 512 : 256;
   hipLaunchKernelGGL(rmsnorm_f16out_kernel, dim3(rows), dim3(threads), 0, (hipStream_t)stream, in,
-                     weight, static_cast<_Float16*>(out16), dim, eps);
+                     weight, static_cast<_Float16*>(out16), dim, eps KX_BPASS(3, in, weight, out16));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -511,7 +515,7 @@ extern "C" int kx_sin_cos_cache_f32(int32_t head_size, int32_t max_seq_len, floa
   if (!sin_cache || !cos_cache || head_size <= 0 || max_seq_len <= 0) return KX_EINVAL;
   const int n = head_size * max_seq_len;
   hipLaunchKernelGGL(sin_cos_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     head_size, max_seq_len, theta, sin_cache, cos_cache);
+                     head_size, max_seq_len, theta, sin_cache, cos_cache KX_BPASS(2, sin_cache, cos_cache));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -530,10 +534,12 @@ extern "C" int kx_rope_bias_f32(int32_t variant, int32_t dim, int32_t kv_dim, in
   const dim3 grid((dim / 2 + 127) / 128, rows);
   if (variant == KX_ROPE_INTERLEAVED) {
     hipLaunchKernelGGL(rope_kernel<KX_ROPE_INTERLEAVED>, grid, dim3(128), 0, (hipStream_t)stream,
-                       dim, kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache, b);
+                       dim, kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache, b
+                       KX_BPASS(8, q, k, sin_cache, cos_cache, bq, bk, bv, v));
   } else if (variant == KX_ROPE_HALF_SPLIT) {
     hipLaunchKernelGGL(rope_kernel<KX_ROPE_HALF_SPLIT>, grid, dim3(128), 0, (hipStream_t)stream, dim,
-                       kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache, b);
+                       kv_dim, head_size, q, k, k_stride, pos, rows, sin_cache, cos_cache, b
+                       KX_BPASS(8, q, k, sin_cache, cos_cache, bq, bk, bv, v));
   } else {
     return KX_EINVAL;
   }
@@ -552,7 +558,7 @@ extern "C" int kx_swiglu_f32(const float* in1, const float* in2, float* out, int
                              void* stream) {
   if (!in1 || !in2 || !out || n <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(swiglu_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in1,
-                     in2, out, n);
+                     in2, out, n KX_BPASS(3, in1, in2, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -560,7 +566,7 @@ extern "C" int kx_swiglu_f32(const float* in1, const float* in2, float* out, int
 extern "C" int kx_add_f32(const float* a, const float* b, float* out, int32_t n, void* stream) {
   if (!a || !b || !out || n <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b,
-                     out, n);
+                     out, n KX_BPASS(3, a, b, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -569,7 +575,7 @@ extern "C" int kx_embedding_f32(const int32_t* tokens, int32_t n_tokens, const f
                                 int32_t dim, int32_t vocab_size, float* out, void* stream) {
   if (!tokens || !table || !out || n_tokens <= 0 || dim <= 0 || vocab_size <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(embedding_kernel, dim3(n_tokens), dim3(256), 0, (hipStream_t)stream, tokens,
-                     table, out, dim, vocab_size);
+                     table, out, dim, vocab_size KX_BPASS(3, tokens, table, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -577,7 +583,7 @@ extern "C" int kx_embedding_f32(const int32_t* tokens, int32_t n_tokens, const f
 extern "C" int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index, void* stream) {
   if (!logits || !out_index || n <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n,
-                     out_index);
+                     out_index KX_BPASS(2, logits, out_index));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -592,6 +598,9 @@ static int step_pick_launch(kx::StepArgs a, void* workspace, size_t workspace_by
   a.pi = reinterpret_cast<int32_t*>(a.pv + kx::kStepBlocks);
   a.ticket = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kStepTicketOff);
   const int blocks = a.n < kx::kStepBlocks * 256 ? (a.n + 255) / 256 : kx::kStepBlocks;
+  KX_BSET(a, SB_LOGITS, a.logits); KX_BSET(a, SB_PV, a.pv); KX_BSET(a, SB_PI, a.pi); KX_BSET(a, SB_TICKET, a.ticket);
+  KX_BSET(a, SB_CAND, a.cand); KX_BSET(a, SB_TOKEN, a.token); KX_BSET(a, SB_POS, a.pos);
+  KX_BSET(a, SB_HISTORY, a.history); KX_BSET(a, SB_TABLE, a.table); KX_BSET(a, SB_XOUT, a.x_out);
   hipLaunchKernelGGL(kx::step_pick_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   KX_LAUNCH_CHECK();
   return KX_OK;
@@ -641,8 +650,11 @@ extern "C" int kx_decode_step_end_candidates_embed(const float* candidates, int3
   a.token = token_dev; a.pos = pos_dev; a.history = history_dev; a.history_len = history_len;
   a.write_history = write_history != 0;
   a.table = table; a.dim = dim; a.vocab = vocab_size; a.x_out = x_out;
+  KX_BSET(a, SB_LOGITS, nullptr); KX_BSET(a, SB_PV, nullptr); KX_BSET(a, SB_PI, nullptr); KX_BSET(a, SB_TICKET, nullptr);
+  KX_BSET(a, SB_CAND, nullptr); KX_BSET(a, SB_TOKEN, a.token); KX_BSET(a, SB_POS, a.pos);
+  KX_BSET(a, SB_HISTORY, a.history); KX_BSET(a, SB_TABLE, a.table); KX_BSET(a, SB_XOUT, a.x_out);
   hipLaunchKernelGGL(kx::step_end_candidates_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                     candidates, ranks, a);
+                     candidates, ranks, a KX_BPASS(1, candidates));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -658,7 +670,7 @@ extern "C" int kx_fill_hash_i8(int8_t* dst, int32_t rows, int32_t cols, int64_t 
                                int64_t col0, uint64_t seed, void* stream) {
   if (!dst || rows <= 0 || cols <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(fill_hash_i8_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dst, rows,
-                     cols, ld, row0, col0, seed);
+                     cols, ld, row0, col0, seed KX_BPASS(1, dst));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -667,7 +679,7 @@ extern "C" int kx_fill_hash_f32(float* dst, int32_t rows, int32_t cols, int64_t 
                                 int64_t col0, uint64_t seed, float lo, float hi, void* stream) {
   if (!dst || rows <= 0 || cols <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(fill_hash_f32_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dst, rows,
-                     cols, ld, row0, col0, seed, lo, hi);
+                     cols, ld, row0, col0, seed, lo, hi KX_BPASS(1, dst));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -677,7 +689,7 @@ extern "C" int kx_embedding_dpos_f32(const int32_t* history_dev, const int32_t* 
                                      float* out, void* stream) {
   if (!history_dev || !pos_dev || !table || !out || dim <= 0 || vocab_size <= 0) return KX_EINVAL;
   hipLaunchKernelGGL(embedding_dpos_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, history_dev,
-                     pos_dev, table, out, dim, vocab_size);
+                     pos_dev, table, out, dim, vocab_size KX_BPASS(4, history_dev, pos_dev, table, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -687,7 +699,7 @@ extern "C" int kx_swiglu_rows_f32(const float* in, int64_t ld_in, int32_t half, 
   if (!in || !out || half <= 0 || rows <= 0) return KX_EINVAL;
   if (half % 4 || ld_in % 4 || ld_out % 4 || ((uintptr_t)in | (uintptr_t)out) % 16) return KX_EINVAL;
   hipLaunchKernelGGL(swiglu_rows_kernel<float>, dim3(2048), dim3(256), 0, (hipStream_t)stream, in, ld_in,
-                     half, out, ld_out, rows);
+                     half, out, ld_out, rows KX_BPASS(2, in, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -699,21 +711,21 @@ extern "C" int kx_swiglu_rows_f16out(const float* in, int64_t ld_in, int32_t hal
   const int64_t n4 = (int64_t)rows * (half / 4);
   hipLaunchKernelGGL(swiglu_rows_kernel<_Float16>, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)),
                      dim3(256), 0, (hipStream_t)stream, in, ld_in, half, static_cast<_Float16*>(out16), ld_out,
-                     rows);
+                     rows KX_BPASS(2, in, out16));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
 
 extern "C" int kx_scale_f32(float scale, float* x, int32_t n, void* stream) {
   if (!x || n <= 0) return KX_EINVAL;
-  hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scale, x, n);
+  hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scale, x, n KX_BPASS(1, x));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
 
 extern "C" int kx_softmax_f32(float* x, int32_t n, void* stream) {
   if (!x || n <= 0) return KX_EINVAL;
-  hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(n > 4096 ? 1024 : 256), 0, (hipStream_t)stream, x, n);
+  hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(n > 4096 ? 1024 : 256), 0, (hipStream_t)stream, x, n KX_BPASS(1, x));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -722,7 +734,7 @@ extern "C" int kx_scale_sum_f32(const float* value, const float* scale, float* o
                                 int32_t size, int32_t stride, void* stream) {
   if (!value || !scale || !out || pos < 0 || size <= 0 || stride < size) return KX_EINVAL;
   hipLaunchKernelGGL(scale_sum_kernel, dim3((size + 63) / 64), dim3(64), 0, (hipStream_t)stream, value,
-                     scale, out, pos, size, stride);
+                     scale, out, pos, size, stride KX_BPASS(3, value, scale, out));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -733,7 +745,7 @@ extern "C" int kx_quantize_q80_f32(const float* w, size_t n, int32_t group_size,
   const size_t groups = n / (size_t)group_size;
   if ((groups + 3) / 4 > 0x7fffffffull) return KX_EINVAL;
   hipLaunchKernelGGL(quantize_q80_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, w, groups, group_size, q, scales);
+                     (hipStream_t)stream, w, groups, group_size, q, scales KX_BPASS(3, w, q, scales));
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("KX_HIP_LIB") or os.path.join(os.path.dirname(_PKG), "lib", "libkx_hip.so")
+# KX_LIB_DIR selects another build of both libraries (lib_bounds: the bounds-checking build)
+LIB_DIR = os.environ.get("KX_LIB_DIR") or os.path.join(os.path.dirname(_PKG), "lib")
+LIB_PATH = os.environ.get("KX_HIP_LIB") or os.path.join(LIB_DIR, "libkx_hip.so")
 
 ROPE_INTERLEAVED = 0
 ROPE_HALF_SPLIT = 1
@@ -53,6 +55,9 @@ SIGNATURES = {
     "kx_graph_end_capture": (C.c_int, [_vp, C.POINTER(_vp)]),
     "kx_graph_launch": (C.c_int, [_vp, _vp]),
     "kx_graph_destroy": (C.c_int, [_vp]),
+    "kx_bounds_enabled": (C.c_int, []),
+    "kx_bounds_report": (C.c_int, [_vp, _i32, C.POINTER(C.c_uint64)]),
+    "kx_bounds_reset": (C.c_int, []),
     "kx_gemv_w8_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "kx_gemv_w8_f32_ex": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
                                     _i32, _vp]),
@@ -163,6 +168,32 @@ class GemvDesc(C.Structure):
 
 
 GEMV_PLAIN, GEMV_GATE_UP, GEMV_QKV_ROPE = 0, 1, 2
+
+
+class BoundsRecord(C.Structure):
+    """kx_bounds_record of include/kx_hip.h."""
+    _fields_ = [("file_id", C.c_int32), ("line", C.c_int32), ("operand", C.c_int32), ("pad_", C.c_int32),
+                ("offset", C.c_int64), ("extent", C.c_int64)]
+
+
+BOUNDS_FILES = {1: "gemv_w8.hip", 2: "gemm_w8_rows.hip", 3: "gemm_w8.hip", 4: "gemm_f16.hip",
+                5: "attn_decode.hip", 6: "attn_prefill.hip", 7: "support.hip", 8: "gemv_f32.hip"}
+
+
+def bounds_enabled():
+    return bool(lib().kx_bounds_enabled())
+
+
+def bounds_report(reset=False):
+    """(total violations, [(file, line, operand, offset, extent), ...]) of a bounds-checking build."""
+    recs = (BoundsRecord * 1024)()
+    total = C.c_uint64(0)
+    check(lib().kx_bounds_report(recs, 1024, C.byref(total)), "kx_bounds_report")
+    out = [(BOUNDS_FILES.get(r.file_id, str(r.file_id)), r.line, r.operand, r.offset, r.extent)
+           for r in recs[:min(total.value, 1024)]]
+    if reset:
+        check(lib().kx_bounds_reset(), "kx_bounds_reset")
+    return total.value, out
 
 
 def lib():

@@ -5,10 +5,9 @@ import os
 
 import numpy as np
 
-from . import KxError, lib as _kxlib
+from . import KxError, LIB_DIR, lib as _kxlib
 
-_PKG = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libkx_host.so")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libkx_host.so")
 
 ROPE_INTERLEAVED, ROPE_HALF_SPLIT = 0, 1
 

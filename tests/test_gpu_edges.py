@@ -111,3 +111,25 @@ def test_randomised_model_sweep_fixed_seed(capfd):
     import fuzz_model
     assert fuzz_model.run(60, 42)     # the sweep that found the rotary-table read == 0
     assert fuzz_model.run(20, 20262, head_sizes=(64, 128)) == 0
+
+
+def test_bounds_build_sees_a_read_past_a_scale_array():
+    # the self-test of the bounds-checking build: a scale array one group short makes the last row's
+    # last load reach 4 bytes past its allocation -- invisible to parity, recorded by the checker
+    # (and then cleared, so the run's final report stays about the library, not about this test)
+    if not kx.bounds_enabled():
+        pytest.skip("not the bounds-checking build (make BOUNDS=1, KX_LIB_DIR=.../lib_bounds)")
+    before, _ = kx.bounds_report()
+    K, M = 64, 1024
+    rng = np.random.default_rng(0)
+    dx = kx.Buf.from_numpy(rng.standard_normal(M).astype(np.float32))
+    dw = kx.Buf.from_numpy(rng.integers(-127, 128, (K, M), dtype=np.int8))
+    ds = kx.Buf.from_numpy(np.ones(K * M // GS - 1, np.float32))      # one scale short
+    dy = kx.Buf.zeros(K)
+    kx.check(kx.lib().kx_gemv_w8_f32(dx.ptr, dw.ptr, ds.ptr, GS, dy.ptr, M, K, None), "kx_gemv_w8_f32")
+    total, recs = kx.bounds_report()
+    new = recs[before:] if before < 1024 else []
+    assert total > before and new
+    assert all(r[0] == "gemv_w8.hip" and r[2] == 2 and r[3] == r[4] for r in new), new[:4]
+    if before == 0:
+        kx.check(kx.lib().kx_bounds_reset(), "kx_bounds_reset")
