@@ -29,7 +29,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "llm-inference-engine_amd"))
+# KX_BENCH_PACKAGE_DIR: the directory that holds the kx package (a test points it at a GPU-less
+# stand-in to rehearse the multi-rank control flow on CPU processes)
+sys.path.insert(0, os.environ.get("KX_BENCH_PACKAGE_DIR") or os.path.join(ROOT, "llm-inference-engine_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix peak
@@ -199,9 +201,20 @@ def prefill_kernels(kx, shape, tp, T=4096):
     }
 
 
-def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
-    """Times the CPU oracle's W8 GEMV (the port of the reference formula) on the host cores on a
-    bounded sample: the model's widest layer matrix, repeated until ~budget_s has elapsed."""
+def _host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+
+
+def cpu_baseline(model_name, bytes_per_token, context, group_size=64, budget_s=12.0):
+    """Times the CPU oracle (the port of the reference formulas: scalar C, double accumulation,
+    OpenMP over output rows / heads) on the host cores, on a bounded sample of the decode step:
+    the W8 GEMV on the model's widest layer matrix, repeated for ~budget_s, and the decode
+    attention of one layer over `context` cached keys.  tok/s = 1 / (linear bytes per token / GEMV
+    bytes per second + layers x attention time)."""
     from kx import host
     from oracle import kxo
     shape = host.MODEL_SHAPES[model_name]
@@ -210,11 +223,7 @@ def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
     w = rng.integers(-127, 128, size=(K, M), dtype=np.int8)
     s = rng.uniform(1e-4, 3e-4, size=K * M // group_size).astype(np.float32)
     x = rng.standard_normal(M).astype(np.float32)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    cores = _host_cores()
     per_call = K * M + 4 * K * M // group_size + 4 * (M + K)
     out = {}
     for label, threads in (("1", 1), ("all", cores)):
@@ -226,17 +235,100 @@ def cpu_baseline(model_name, bytes_per_token, group_size=64, budget_s=12.0):
             n += 1
         dt = time.perf_counter() - t0
         out[label] = per_call * n / dt
+    # decode attention of one layer at the benchmark's context (one query row, every head)
+    H, KVH = shape["head_num"], shape["kv_head_num"]
+    hs = shape["dim"] // H
+    keys = max(1, context)
+    kc = rng.standard_normal((1, keys, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, keys, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal((1, H, hs)).astype(np.float32)
+    attn = {}
+    for label, threads in (("1", 1), ("all", cores)):
+        kxo.flash_attention(q, kc, vc, H, KVH, hs, keys, keys - 1, 0, threads=threads)  # warm
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 1.5:
+            kxo.flash_attention(q, kc, vc, H, KVH, hs, keys, keys - 1, 0, threads=threads)
+            n += 1
+        attn[label] = (time.perf_counter() - t0) / n
+    L = shape["layer_num"]
+
+    def tok_s(label):
+        return 1.0 / (bytes_per_token / out[label] + L * attn[label])
     return {
-        "value": out["all"] / bytes_per_token,
+        "value": tok_s("all"),
         "unit": "tok/s",
         "cores": cores,
         "kind": "port",
+        "implementation": "scalar, unvectorised C restatement of the reference formulas (double "
+                          "accumulation of float products), OpenMP over output rows / heads: far under host "
+                          "DRAM bandwidth; a stated baseline, not a target",
         "sample": f"oracle kxo_gemv_w8 on a {K}x{M} int8 matrix (gs {group_size}) repeated for "
-                  f"~{budget_s / 2:.0f}s per setting; tok/s = measured GEMV bytes/s / linear-weight "
-                  f"bytes per token ({bytes_per_token / 1e9:.3f} GB); attention excluded",
+                  f"~{budget_s / 2:.0f}s per setting + oracle decode attention of one layer over {keys} keys "
+                  f"({H} heads, {KVH} kv heads, head {hs}); tok/s = 1 / (linear-weight bytes per token "
+                  f"({bytes_per_token / 1e9:.3f} GB) / GEMV bytes per s + {L} layers x attention time)",
         "gemv_gbps_all_cores": out["all"] / 1e9,
         "gemv_gbps_1_thread": out["1"] / 1e9,
-        "tok_per_s_1_thread": out["1"] / bytes_per_token,
+        "attention_layer_ms_all_cores": attn["all"] * 1e3,
+        "attention_layer_ms_1_thread": attn["1"] * 1e3,
+        "tok_per_s_1_thread": tok_s("1"),
+    }
+
+
+def config1_cpu_token_loop(prompt_tokens=16, decode_tokens=112, one_thread_budget_s=8.0):
+    """The first benchmark configuration: Llama-2 stories110M dims, fp32 weights, greedy decode on
+    the CPU path -- the reference's generate loop (demo/main.cpp:18-41: the prompt one token per
+    step, then argmax steps) over the oracle's token graph, on seeded random-init weights.  All
+    host cores run the whole 16 + 112 steps; one thread (the reference's own code has no threading,
+    its parallelism came from the BLAS under Armadillo) runs as many steps as fit its budget."""
+    from kx import host
+    from oracle import kxo
+    shape = host.MODEL_SHAPES["stories110M"]
+    dim, hid, L, V = shape["dim"], shape["hidden_dim"], shape["layer_num"], shape["vocab_size"]
+    kvd = dim // shape["head_num"] * shape["kv_head_num"]
+    seq_len = prompt_tokens + decode_tokens + 8
+    rng = np.random.default_rng(110)
+
+    def mat(*dims):
+        return (rng.standard_normal(dims, dtype=np.float32) * np.float32(0.02))
+    arrays = {"wq": mat(L, dim, dim), "wk": mat(L, kvd, dim), "wv": mat(L, kvd, dim), "wo": mat(L, dim, dim),
+              "w1": mat(L, hid, dim), "w2": mat(L, dim, hid), "w3": mat(L, hid, dim), "cls": mat(V, dim),
+              "emb": mat(V, dim), "attn_norm": np.ones((L, dim), np.float32),
+              "ffn_norm": np.ones((L, dim), np.float32), "final_norm": np.ones(dim, np.float32)}
+    cfg = kxo.Config(seq_len=seq_len, group_size=0, **shape)
+    weight_bytes = 4 * (sum(a.size for n, a in arrays.items() if n not in ("emb",)))
+    cores = _host_cores()
+    prompt = rng.integers(0, V, prompt_tokens)
+    out = {}
+    streams = {}
+    for label, threads, budget in (("all", cores, None), ("1", 1, one_thread_budget_s)):
+        m = kxo.Model(cfg, arrays=arrays)
+        tok, steps, toks = int(prompt[0]), 0, []
+        t0 = time.perf_counter()
+        for pos in range(prompt_tokens + decode_tokens - 1):
+            logits = m.forward(tok, pos, threads=threads)
+            steps += 1
+            tok = int(prompt[pos + 1]) if pos + 1 < prompt_tokens else int(np.argmax(logits))
+            toks.append(tok)
+            if budget is not None and time.perf_counter() - t0 > budget:
+                break
+        out[label] = (steps, time.perf_counter() - t0)
+        streams[label] = toks
+    n1 = len(streams["1"])
+    return {
+        "workload": f"stories110M dims (dim {dim}, hidden {hid}, {L} layers, {shape['head_num']} heads, vocab {V}), "
+                    f"fp32 weights, {prompt_tokens} prompt + {decode_tokens} greedy steps, CPU oracle token loop",
+        "steps_per_s_all_cores": out["all"][0] / out["all"][1],
+        "cores": cores,
+        "steps_all_cores": out["all"][0],
+        "steps_per_s_1_thread": out["1"][0] / out["1"][1],
+        "steps_1_thread": out["1"][0],
+        "weight_gbps_all_cores": weight_bytes * out["all"][0] / out["all"][1] / 1e9,
+        "same_tokens_1_thread_vs_all_cores": streams["1"] == streams["all"][:n1],
+        "kind": "port",
+        "implementation": "scalar, unvectorised C (double accumulation), OpenMP over output rows",
+        "published_reference": "673.89 / 955 steps/s on an RTX 3090 CUDA path (reports/07, reports/10): another "
+                               "device and a degenerate-output run, not comparable",
     }
 
 
@@ -299,7 +391,9 @@ def main():
     if args.one_gpu_rehearsal:
         local_rank, args.context = 0, 0
     kx.check(kx.lib().kx_set_device(local_rank), "kx_set_device")
-    torch.cuda.set_device(local_rank)
+    have_gpu = torch.cuda.is_available()  # false only under the GPU-less stand-in package
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
 
     shape = host.MODEL_SHAPES[args.model]
     seq_len = args.context + args.warmup + args.steps + args.profile_steps + 64
@@ -342,7 +436,8 @@ def main():
         model.init_comm(ids[0])
 
     def fence():
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
@@ -446,10 +541,12 @@ def main():
                 # others waiting; the ranks start together behind the previous agreement
                 model.set_state(start_token, start_pos)
                 model.decode(max(args.warmup, 2), use_graph=use_graph)
-                torch.cuda.synchronize()
+                if have_gpu:
+                    torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 model.decode(args.steps, use_graph=use_graph)
-                torch.cuda.synchronize()
+                if have_gpu:
+                    torch.cuda.synchronize()
                 state["elapsed"] = time.perf_counter() - t0
                 state["allreduce_us"] = model.profile_allreduce(shape["dim"], 200) * 1e3
 
@@ -547,7 +644,8 @@ def main():
         if not args.no_prefill_kernels:
             line["prefill_kernels"] = prefill_kernels(kx, shape, world)
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed at N=1 only
-            line["cpu_baseline"] = cpu_baseline(args.model, bpt)
+            line["cpu_baseline"] = cpu_baseline(args.model, bpt, args.context)
+            line["config1"] = config1_cpu_token_loop()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -109,7 +109,7 @@ def test_randomised_kernel_sweep_fixed_seed():
 
 def test_randomised_model_sweep_fixed_seed(capfd):
     import fuzz_model
-    assert fuzz_model.run(60, 42)     # the sweep that found the rotary-table read == 0
+    assert fuzz_model.run(60, 42) == 0     # the sweep that found the rotary-table read
     assert fuzz_model.run(20, 20262, head_sizes=(64, 128)) == 0
 
 
