@@ -120,7 +120,9 @@ int kx_gemv_w8_swiglu_f32(const float* x, const int8_t* w13, const float* scales
  * v written into their KV-cache row: y1/y2 point at the layer's [seq_len][kv_dim] block and are
  * advanced by pos*kv_pos_stride elements (model.cpp:237-245).  `pos_dev` (device int32) is read
  * by the kernel when non-null, so a captured graph can be replayed as the position advances;
- * otherwise `pos` is used.  Unused pointer fields are NULL, unused ints 0. */
+ * otherwise `pos` is used.  Unused pointer fields are NULL, unused ints 0.  Precondition for
+ * KX_GEMV_QKV_ROPE: the sin/cos tables hold at least (position + 1) rows of head_size floats and the
+ * cache blocks at least (position + 1) rows of kv_pos_stride elements. */
 enum { KX_GEMV_PLAIN = 0, KX_GEMV_GATE_UP = 1, KX_GEMV_QKV_ROPE = 2 };
 typedef struct kx_gemv_w8_desc {
   int32_t mode;         /* KX_GEMV_* */
@@ -257,7 +259,10 @@ int kx_gemm_w8_rows_f16act(const void* X16, int64_t ldx, const int8_t* w, const 
  *   and v columns to the given rows, q and k rotated for position pos0 + t.  head_size 32, 64 or
  *   128, q_dim and kv_dim multiples of 128.
  * Otherwise as kx_gemm_w8_rows_f16act (T <= 192, group size 64, M % 256 == 0);
- * KX_EUNSUPPORTED for other shapes: run the separate launches. */
+ * KX_EUNSUPPORTED for other shapes: run the separate launches.
+ * Preconditions the entries cannot check: the sin/cos tables hold at least pos0 + T rows of
+ * head_size floats, and every leading dimension is at least the width of the rows it strides
+ * (smaller ones are refused with KX_EINVAL). */
 int kx_gemm_w8_rows_swiglu_f16act(const void* X16, int64_t ldx, const int8_t* w13,
                                   const float* scales13, int32_t group_size, void* out16,
                                   int64_t ld_out, int32_t T, int32_t M, int32_t H,
@@ -519,13 +524,17 @@ int kx_comm_allgather_f32(void* comm, const float* sendbuf, float* recvbuf, size
  * slots in rank order (bitwise the same sum on every rank).  Graph-capturable.  Set-up:
  * kx_peer_create on every rank, exchange the kx_peer_handle bytes, kx_peer_connect with all of
  * them ordered by rank, then a host-side barrier before the first collective.  A wait that gives
- * up after 4 s finishes the launch and raises the flag kx_peer_timed_out reads. */
+ * up after 4 s finishes the launch and raises the flag kx_peer_timed_out reads; that rank then stops
+ * posting and marks itself dead in every mailbox, and every rank that waits on it raises its own flag
+ * within one call.  Results of a group are to be trusted only while NO rank's flag is up: a caller
+ * that checks one rank's flag checks them all (bench.py max-reduces them). */
 int kx_peer_create(void** group, int32_t world_size, int32_t rank, size_t max_floats);
 int kx_peer_handle(void* group, void* handle64);
 int kx_peer_connect(void* group, const void* handles);
 /* in place; count <= max_floats (KX_ELIMIT beyond), buf 16-byte aligned */
 int kx_peer_allreduce_sum_f32(void* group, float* buf, size_t count, void* stream);
-/* buf holds world_size x count_per_rank floats, this rank's part already in place */
+/* buf holds world_size x count_per_rank floats, this rank's part already in place (any 4-byte
+ * alignment: parts that do not start on 16 bytes are moved word by word) */
 int kx_peer_allgather_f32(void* group, float* buf, size_t count_per_rank, void* stream);
 int kx_peer_timed_out(void* group, int32_t* flag);
 int kx_peer_destroy(void* group);

@@ -667,7 +667,8 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   unsigned long long* trace = nullptr;
   {
     const size_t used = kTicketBytes + (size_t)kMaxSplits * per_split;
-    if (workspace && workspace_bytes >= used + (size_t)kvh * nsplit * 64 && getenv("KX_ATTN_TRACE"))
+    static const bool env_trace = getenv("KX_ATTN_TRACE") != nullptr;  // read once
+    if (env_trace && workspace && workspace_bytes >= used + (size_t)kvh * nsplit * 64)
       trace = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + used);
   }
   const bool prefetch = cut.longest() > kAttnWaves;

@@ -687,9 +687,8 @@ static int launch_prefill_kernel(const FaArgs& a, int kvh, int threads, int qblo
   constexpr size_t lds = DMA ? 2 * (size_t)(2 * FA_KV * HS * 2)
                              : 2 * (size_t)(FA_KV * (HS + 8) + HS * FA_VT_ROW) * 2;
   static OncePerDevice raised;
-  if (lds > 64 * 1024 && raised.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, DMA>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024)
+    if (int rc = raised.raise(reinterpret_cast<const void*>(&attn_prefill_kernel<HS, DMA>), (int)lds)) return rc;
   const dim3 grid(kvh * (a.kv_mul / a.hpb), qblocks);
   hipLaunchKernelGGL((attn_prefill_kernel<HS, DMA>), grid, dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();

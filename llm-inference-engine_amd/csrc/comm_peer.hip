@@ -18,7 +18,11 @@
 // The sequence number lives in device memory and is advanced by the kernel, so a launch captured
 // into a HIP graph replays correctly.  Waits are bounded by wall-clock time; a wait that gives up
 // raises a flag the host reads with kx_peer_timed_out() and the launch finishes (with a wrong sum)
-// instead of hanging the queue; once the flag is up no later call waits at all.
+// instead of hanging the queue; once the flag is up no later call waits at all.  A rank whose flag
+// is up stops posting data and sequence numbers and writes a "dead" word into every mailbox
+// instead; a rank that finds a dead word while it waits raises its own flag at once (and passes the
+// word on the same way), so one rank's failure shows in EVERY rank's kx_peer_timed_out() within
+// one call -- no rank is left trusting sums that another rank no longer takes part in.
 #include <string.h>
 
 #include "kx_common.hpp"
@@ -53,6 +57,10 @@ __device__ __forceinline__ unsigned* peer_flag(char* box, size_t flags_off, unsi
                                                int src) {
   return reinterpret_cast<unsigned*>(box + flags_off + ((size_t)par * world + src) * kPeerFlagStride);
 }
+// behind the 2 x world sequence flags: one "dead" word per source rank
+__device__ __forceinline__ unsigned* peer_dead(char* box, size_t flags_off, int world, int src) {
+  return reinterpret_cast<unsigned*>(box + flags_off + ((size_t)2 * world + src) * kPeerFlagStride);
+}
 
 // GATHER: buf holds world x count floats, this rank's part at buf + rank * count; every part is
 // filled in.  Otherwise buf holds count floats and receives the sum over the ranks.
@@ -69,8 +77,16 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float
   const unsigned seq = s_seq, par = seq & 1u;
   const bool dead = s_dead != 0;
   const float* mine = GATHER ? buf + (size_t)rank * count : buf;
-  // 1. this rank's vector into its slot of every mailbox
-  const int n4 = count >> 2;
+  if (dead) {
+    // out of the protocol: tell every rank so (again: cheap, and a rank that connected late sees it)
+    if ((int)threadIdx.x < world)
+      __hip_atomic_store(peer_dead(ctx->box[threadIdx.x], flags_off, world, rank), 1u, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) ctx->seq = seq;
+    return;
+  }
+  // 1. this rank's vector into its slot of every mailbox (16-byte pieces where its rows allow)
+  const int n4 = ((uintptr_t)mine % 16 == 0) ? count >> 2 : 0;
   for (int i = threadIdx.x; i < n4; i += blockDim.x) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(mine + 4 * i);
     for (int p = 0; p < world; ++p)
@@ -86,19 +102,28 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float
   if ((int)threadIdx.x < world)
     __hip_atomic_store(peer_flag(ctx->box[threadIdx.x], flags_off, par, world, rank), seq,
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  // 3. wait for every rank's number in the own mailbox
-  if ((int)threadIdx.x < world && !dead) {
+  // 3. wait for every rank's number in the own mailbox -- or for word that the rank has left
+  __shared__ unsigned s_gave_up;
+  if (threadIdx.x == 0) s_gave_up = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < world) {
     unsigned* f = peer_flag(ctx->box[rank], flags_off, par, world, (int)threadIdx.x);
+    unsigned* d = peer_dead(ctx->box[rank], flags_off, world, (int)threadIdx.x);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kPeerWaitTicks) {
+      if (__hip_atomic_load(d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0 ||
+          __builtin_amdgcn_s_memrealtime() - t0 > kPeerWaitTicks) {
         ctx->timed_out = 1;
+        s_gave_up = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
   __syncthreads();
+  if (s_gave_up && (int)threadIdx.x < world)  // this rank leaves too: pass the word on right away
+    __hip_atomic_store(peer_dead(ctx->box[threadIdx.x], flags_off, world, rank), 1u, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope: the slots as the other ranks wrote them
   // 4. slots in rank order
   char* own = ctx->box[rank];
@@ -109,7 +134,7 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float
       for (int i = threadIdx.x; i < count; i += blockDim.x) buf[(size_t)q * count + i] = s[i];
     }
   } else {
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    for (int i = threadIdx.x; i < (count >> 2); i += blockDim.x) {
       f32x4 acc = *reinterpret_cast<const f32x4*>(peer_slot(own, par, world, 0, cap) + 4 * i);
       for (int q = 1; q < world; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(peer_slot(own, par, world, q, cap) + 4 * i);
@@ -117,7 +142,7 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float
       }
       *reinterpret_cast<f32x4*>(buf + 4 * i) = acc;
     }
-    for (int i = 4 * n4 + threadIdx.x; i < count; i += blockDim.x) {
+    for (int i = 4 * (count >> 2) + threadIdx.x; i < count; i += blockDim.x) {
       float acc = peer_slot(own, par, world, 0, cap)[i];
       for (int q = 1; q < world; ++q) acc += peer_slot(own, par, world, q, cap)[i];
       buf[i] = acc;
@@ -142,7 +167,7 @@ extern "C" int kx_peer_create(void** group, int32_t world_size, int32_t rank, si
   g->device = device;
   g->cap = (max_floats + 63) / 64 * 64;
   g->flags_off = 2 * (size_t)world_size * g->cap * sizeof(float);
-  g->box_bytes = g->flags_off + 2 * (size_t)world_size * kx::kPeerFlagStride;
+  g->box_bytes = g->flags_off + 3 * (size_t)world_size * kx::kPeerFlagStride;  // 2 x world flags + world dead words
   void* box = nullptr;
   // memory the other ranks write while this rank's kernel runs: fine-grained (coherent within a
   // kernel's lifetime), not the default coarse-grained kind (coherent at kernel boundaries only)

@@ -803,9 +803,7 @@ static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_b
   const int tiles = tiles_m * tiles_n;
   // 128 KiB of dynamic LDS needs the opt-in, once per kernel and device
   static OncePerDevice opted_in;  // one instance per kernel
-  if (opted_in.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_BUF));
+  if (int rc = opted_in.raise(reinterpret_cast<const void*>(KERN), 2 * GP_BUF)) return rc;
   int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, a.T, split_ws_bytes) : 1;
   if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
     const int want = atoi(e);

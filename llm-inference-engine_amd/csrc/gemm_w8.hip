@@ -209,9 +209,7 @@ int gemm_w8_launch(const GemmW8Args& a, hipStream_t s) {
   const int tiles_m = (a.T + GM_BM - 1) / GM_BM, tiles_n = (a.K + GM_BN - 1) / GM_BN;
   constexpr size_t lds = 2 * (2 * GM_BM * GM_LDS_ROW * 2 + GM_BN * 4);
   static OncePerDevice raised;
-  if (raised.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w8_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int rc = raised.raise(reinterpret_cast<const void*>(&gemm_w8_kernel), (int)lds)) return rc;
   hipLaunchKernelGGL(gemm_w8_kernel, dim3(tiles_m * tiles_n), dim3(256), lds, s, a);
   KX_LAUNCH_CHECK();
   return KX_OK;

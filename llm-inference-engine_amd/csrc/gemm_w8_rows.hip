@@ -492,9 +492,7 @@ template <int TB, int PAIR>
 static int launch_rows(const RowsArgs& a, hipStream_t s) {
   static OncePerDevice raised;
   constexpr int lds = rows_lds_bytes<TB>();
-  if (raised.first())
-    KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w8_rows_kernel<TB, PAIR>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (int rc = raised.raise(reinterpret_cast<const void*>(&gemm_w8_rows_kernel<TB, PAIR>), lds)) return rc;
   const int tiles = a.mode == ROWS_SWIGLU ? a.half / 64 : (a.K + FR_BN - 1) / FR_BN;
   hipLaunchKernelGGL((gemm_w8_rows_kernel<TB, PAIR>), dim3(tiles * a.nsplit), dim3(64 * (4 * PAIR + 1)), lds, s,
                      a);
@@ -525,6 +523,10 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   if ((k0 < K && !y1 && k1 > k0) || (k1 < K && !y2)) return KX_EINVAL;
   const int xalign = x_half ? 8 : 4;
   // M % 256: a row's scales then start on a 16-byte boundary
+  // leading dimensions that could not hold the rows they are given would make the kernel read or
+  // write the neighbouring rows (and past the buffer on the last one)
+  if (ldx < M || (residual && ldr < k0) || (mode != ROWS_SWIGLU && (ld0 < k0 || (y1 && ld1 < k1 - k0) || (y2 && ld2 < K - k1))))
+    return KX_EINVAL;
   if (T > 192 || group_size != 64 || M % 256 != 0 || ldx % xalign != 0 || ((uintptr_t)X % 16) != 0 ||
       ((uintptr_t)w % 16) != 0 || ((uintptr_t)scales % 16) != 0)
     return KX_EUNSUPPORTED;
@@ -549,7 +551,7 @@ static int rows_run(const void* X, bool x_half, int64_t ldx, const int8_t* w, co
   const int TB = T <= 16 ? 1 : T <= 32 ? 2 : T <= 64 ? 4 : T <= 96 ? 6 : T <= 128 ? 8 : T <= 160 ? 10 : 12;
   const size_t slab_bytes = have_ws ? split_ws_bytes - kRowsTicketBytes - kRowsX16Bytes : 0;
   int S = rows_split_choice(tiles, nu, TB, slab_bytes);
-  if (const char* e = getenv("KX_ROWS_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
+  if (const char* e = getenv("KX_ROWS_SPLIT")) {  // A/B runs and tests (which switch it between calls): 1, 2, 4, 8 or 16
     const int want = atoi(e);
     if (want == 1 || ((want == 2 || want == 4 || want == 8 || want == 16) && nu >= want &&
                       (size_t)tiles * want * TB * 8192 <= slab_bytes))

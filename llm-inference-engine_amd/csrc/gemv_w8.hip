@@ -455,9 +455,7 @@ static int launch(const GemvW8Args& a, int threads, hipStream_t s) {
   const size_t lds = (size_t)a.chunks * 1024 * sizeof(float);
   if (lds > 64 * 1024) {
     static OncePerDevice raised;  // per instantiation; the attribute is sticky
-    if (raised.first())
-      KX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_w8_kernel<R, U, MODE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    if (int rc = raised.raise(reinterpret_cast<const void*>(&gemv_w8_kernel<R, U, MODE>), 160 * 1024 - 64)) return rc;
   }
   hipLaunchKernelGGL((gemv_w8_kernel<R, U, MODE>), dim3(grid), dim3(threads), lds, s, a);
   KX_LAUNCH_CHECK();

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <initializer_list>
+#include <mutex>
 
 #include "../../include/kx_hip.h"
 
@@ -14,15 +16,23 @@ __device__ __forceinline__ _Float16 sat_f16(float x) {
 }
 
 // A kernel's raised dynamic-LDS limit (hipFuncSetAttribute) holds for the device that was current
-// when it was set: one flag per device and call site.  first() is true once per device.
+// when it was set: one flag per device and call site.  raise() sets the attribute the first time a
+// device comes by and returns the HIP status; the flag goes up only after the call succeeded, under
+// a lock, so neither a second host thread (ranks of one process) nor a retry after a failure can
+// launch ahead of the attribute.
 struct OncePerDevice {
-  bool done[64] = {};
-  bool first() {
+  std::atomic<bool> done[64] = {};
+  std::mutex mu;
+  int raise(const void* kernel, int lds_bytes) {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;  // unknown: set it again
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
+    const bool known = hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64;
+    if (known && done[d].load(std::memory_order_acquire)) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (known && done[d].load(std::memory_order_relaxed)) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    if (known) done[d].store(true, std::memory_order_release);
+    return 0;
   }
 };
 

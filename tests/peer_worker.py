@@ -128,6 +128,17 @@ def absent_rank(rank, world, dist, count):
         second_s = time.perf_counter() - t0
         ok = flag.value == 1 and 2.0 < first_s < 20.0 and second_s < 1.0
     dist.barrier()
+    if rank != 0:
+        # rank 0 has left the protocol and said so in every mailbox: a rank that reduces now must
+        # not trust the sum -- its own flag goes up within this one call, without a 4 s wait
+        buf = kx.Buf.from_numpy(np.ones(count, np.float32))
+        t0 = time.perf_counter()
+        kx.check(L.kx_peer_allreduce_sum_f32(g, buf.ptr, count, st.ptr), "peer_allreduce")
+        st.sync()
+        first_s = time.perf_counter() - t0
+        kx.check(L.kx_peer_timed_out(g, C.byref(flag)), "peer_timed_out")
+        ok = flag.value == 1 and first_s < 1.5
+    dist.barrier()
     kx.check(L.kx_peer_destroy(g), "peer_destroy")
     print(json.dumps({"rank": rank, "ok": bool(ok), "timed_out": 0, "flag": flag.value, "first_s": first_s,
                       "second_s": second_s}), flush=True)
@@ -183,6 +194,14 @@ def main():
     st.sync()
     gathered = gb.numpy(np.float32, (world, 2))
     ok &= bool(np.array_equal(gathered, np.array([[r + 0.5, 100 + r] for r in range(world)], np.float32)))
+    # parts of six floats: an odd rank's part starts 8 bytes off a 16-byte boundary
+    parts6 = np.zeros((world, 6), np.float32)
+    parts6[rank] = np.arange(6) + 10 * rank
+    gb6 = kx.Buf.from_numpy(parts6)
+    kx.check(L.kx_peer_allgather_f32(g, gb6.ptr, 6, st.ptr), "peer_allgather")
+    st.sync()
+    ok &= bool(np.array_equal(gb6.numpy(np.float32, (world, 6)),
+                              np.array([np.arange(6) + 10 * r for r in range(world)], np.float32)))
     # a captured launch replayed: x <- sum over ranks of x, three times: x0 * world^3 (exact in fp32
     # for these small integers)
     n = min(count, 2048)

@@ -57,10 +57,13 @@ def test_peer_collectives_across_processes(world, count):
 
 
 @pytest.mark.gpu
-def test_peer_wait_gives_up_when_a_rank_is_absent():
-    # the bounded wait: a reduce whose partner never shows up ends after 4 s with the flag raised,
-    # and later calls on that group do not wait again
-    _run_ranks(2, 1024, ("absent",))
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_wait_gives_up_when_a_rank_is_absent(world):
+    # the bounded wait: a reduce whose partners never show up ends after 4 s with the flag raised,
+    # and later calls on that group do not wait again; the rank that gave up marks itself dead in
+    # every mailbox, so the other ranks' next call raises THEIR flags at once (no healthy rank is
+    # left adding the slots of a rank that has stopped taking part)
+    _run_ranks(world, 1024, ("absent",))
 
 
 @pytest.mark.gpu
