@@ -119,6 +119,11 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(PeerDev* ctx, float
       }
       __builtin_amdgcn_s_sleep(2);
     }
+    // a source that has left counts even when its number for THIS call did arrive before it went
+    if (__hip_atomic_load(d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+      ctx->timed_out = 1;
+      s_gave_up = 1;
+    }
   }
   __syncthreads();
   if (s_gave_up && (int)threadIdx.x < world)  // this rank leaves too: pass the word on right away
