@@ -78,7 +78,7 @@ int kx_graph_destroy(void* graph_exec);
  * record holds) to the host after a device synchronise; kx_bounds_reset clears the record.  In a
  * normal build kx_bounds_enabled() is 0 and the other two return KX_EUNSUPPORTED.
  * file_id: 1 gemv_w8, 2 gemm_w8_rows, 3 gemm_w8, 4 gemm_f16, 5 attn_decode, 6 attn_prefill,
- * 7 support, 8 gemv_f32; operand: the index the kernel file gives the buffer; offset: byte offset
+ * 7 support, 8 gemv_f32, 9 gemv_engine; operand: the index the kernel file gives the buffer; offset: byte offset
  * of the access from the block's start; extent: the block's size in bytes. */
 typedef struct kx_bounds_record {
   int32_t file_id, line, operand, pad_;
@@ -150,6 +150,28 @@ typedef struct kx_gemv_w8_desc {
   int32_t kv_f16;        /* non-zero: y1/y2 are fp16 cache blocks (16-bit KV cache); values are rounded once */
 } kx_gemv_w8_desc;
 int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* desc, void* stream);
+
+/* Two consecutive GEMVs of the token loop's chain in ONE persistent launch (no counterpart in the
+ * reference, which launches every MatmulLayer::forward on its own, llama3.cpp:648-788): ops[0] is a
+ * kx_gemv_w8_fused_f32 description whose input vector is in memory; ops[1] (optional) takes the
+ * output vector of ops[0] as its input (x = NULL or ops[0].y0) with its own fused RMSNorm and
+ * epilogue.  One workgroup per CU streams its rows of BOTH matrices through an LDS ring without
+ * stopping at the seam; ops[0]'s outputs cross the seam as 8-byte {value, tag} words in `workspace`
+ * (kx_gemv_w8_chain_workspace_bytes(rows of ops[0]'s output), 256-byte aligned) besides being
+ * stored to ops[0].y0 as usual.  tag = (position + 1) * 128 + chain_id (0..127): give every seam of
+ * a token its own chain_id, and call kx_gemv_w8_chain_reset whenever the position is set to
+ * anything but its successor (and once after allocating the workspace).  The position is read from
+ * pos_dev when non-null (graph replay), else `pos`.  Results equal kx_gemv_w8_fused_f32's formulas
+ * (the 16 products of a lane summed, times the group scale; the row sum in another order).
+ * group_size 64, M % 1024 == 0, K % 8 == 0, head sizes that are powers of two; KX_EUNSUPPORTED
+ * otherwise (run the single launches).  The launch needs every CU of the device to itself.  Every
+ * in-kernel wait is bounded (1 s); one that gave up is reported by kx_gemv_w8_chain_status. */
+size_t kx_gemv_w8_chain_workspace_bytes(int32_t max_rows);
+int kx_gemv_w8_chain_reset(void* workspace, size_t workspace_bytes, void* stream);
+int kx_gemv_w8_chain_status(void* workspace, int32_t* gave_up);
+int kx_gemv_w8_chain_f32(const kx_gemv_w8_desc* ops, int32_t nops, void* workspace,
+                         size_t workspace_bytes, int32_t chain_id, const int32_t* pos_dev, int32_t pos,
+                         void* stream);
 
 /* ---------------- fp32 GEMV ----------------
  * Replaces matmul_kernel_cu / matmul_kernel_cu_fp32 (cuda/matmul_kernel.cu:6-54,89-109) and

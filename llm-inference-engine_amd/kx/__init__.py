@@ -62,6 +62,10 @@ SIGNATURES = {
     "kx_gemv_w8_f32_ex": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
                                     _i32, _vp]),
     "kx_gemv_w8_swiglu_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "kx_gemv_w8_chain_workspace_bytes": (_sz, [_i32]),
+    "kx_gemv_w8_chain_reset": (C.c_int, [_vp, _sz, _vp]),
+    "kx_gemv_w8_chain_status": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "kx_gemv_w8_chain_f32": (C.c_int, [_vp, _i32, _vp, _sz, _i32, _vp, _i32, _vp]),
     "kx_gemv_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "kx_gemm_w8_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "kx_gemm_w8_f32_ex": (C.c_int, [_vp, C.c_int64, _vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_int64, _vp,
@@ -177,7 +181,8 @@ class BoundsRecord(C.Structure):
 
 
 BOUNDS_FILES = {1: "gemv_w8.hip", 2: "gemm_w8_rows.hip", 3: "gemm_w8.hip", 4: "gemm_f16.hip",
-                5: "attn_decode.hip", 6: "attn_prefill.hip", 7: "support.hip", 8: "gemv_f32.hip"}
+                5: "attn_decode.hip", 6: "attn_prefill.hip", 7: "support.hip", 8: "gemv_f32.hip",
+                9: "gemv_engine.hip"}
 
 
 def bounds_enabled():
@@ -507,3 +512,25 @@ def quantize_q80(w, group_size=64):
     dq, ds = Buf.zeros(w.size, np.int8), Buf.zeros(w.size // group_size)
     check(lib().kx_quantize_q80_f32(dw.ptr, w.size, group_size, dq.ptr, ds.ptr, None), "kx_quantize_q80_f32")
     return dq.numpy(np.int8, w.shape), ds.numpy(np.float32, (w.size // group_size,))
+
+
+def make_gemv_desc(mode, x, w, s, y0, M, K, group_size=64, norm_w=None, norm_eps=1e-5, y1=None, y2=None, k0=0,
+                   k1=0, bias=None, residual=None, sin=None, cos=None, pos_dev=None, pos=0, rope_variant=0,
+                   head_size=0, kv_pos_stride=0, kv_f16=0):
+    """A kx_gemv_w8_desc from device pointers (ints / None)."""
+    d = GemvDesc()
+    d.mode, d.group_size, d.M, d.K = mode, group_size, M, K
+    d.x, d.w, d.scales, d.norm_w, d.norm_eps = x, w, s, norm_w, norm_eps
+    d.y0, d.y1, d.y2, d.k0, d.k1 = y0, y1, y2, k0, k1
+    d.bias, d.residual = bias, residual
+    d.sin_cache, d.cos_cache, d.pos_dev, d.pos = sin, cos, pos_dev, pos
+    d.rope_variant, d.head_size, d.kv_pos_stride, d.kv_f16 = rope_variant, head_size, kv_pos_stride, kv_f16
+    return d
+
+
+def gemv_chain(descs, workspace, chain_id=0, pos_dev=None, pos=0, stream=None):
+    """kx_gemv_w8_chain_f32 over one or two descriptions; workspace: a Buf sized by
+    kx_gemv_w8_chain_workspace_bytes and reset with kx_gemv_w8_chain_reset."""
+    arr = (GemvDesc * len(descs))(*descs)
+    check(lib().kx_gemv_w8_chain_f32(arr, len(descs), workspace.ptr, workspace.nbytes, chain_id, pos_dev, pos,
+                                     stream), "kx_gemv_w8_chain_f32")

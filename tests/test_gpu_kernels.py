@@ -1259,3 +1259,80 @@ def test_f32_to_f16_rows_strided():
     np.testing.assert_array_equal(got[:, :cols], src[:, :cols].astype(np.float16))
     assert np.all(got[:, cols:] == 7)
     assert kx.lib().kx_f32_to_f16_rows(d_src.ptr, lds, d_dst.ptr, ldd, 62, rows, None) == -1
+
+
+# ---------------- chained GEMVs in one persistent launch ---------------------------------------------
+def _chain_case(rng, dim, hid, H, KVH, hs, variant, pos):
+    ql, kl = H * hs, KVH * hs
+    S = pos + 3
+
+    def w8(K, M):
+        return rng.integers(-127, 128, (K, M), dtype=np.int8), rng.uniform(1e-3, 3e-3, K * M // GS).astype(np.float32)
+    m = dict(wo=w8(dim, ql), w13=w8(2 * hid, dim), w2=w8(dim, hid), qkv=w8(ql + 2 * kl, dim))
+    v = dict(att=rng.standard_normal(ql).astype(np.float32), x=rng.standard_normal(dim).astype(np.float32),
+             g1=rng.uniform(0.5, 1.5, dim).astype(np.float32), g2=rng.uniform(0.5, 1.5, dim).astype(np.float32),
+             bias=(rng.standard_normal(ql + 2 * kl) * 0.1).astype(np.float32))
+    sin, cos = kxo.sin_cos_cache(hs, S, 1e4)
+    return m, v, sin, cos, ql, kl, S
+
+
+@pytest.mark.parametrize("dim,hid,H,KVH,hs,variant,pos", [
+    (1024, 2048, 8, 2, 128, 1, 7), (1024, 3072, 16, 4, 64, 0, 0), (2048, 1024, 16, 16, 128, 1, 33),
+    (1024, 1024, 32, 8, 32, 1, 2)])
+def test_gemv_chain_vs_oracle(dim, hid, H, KVH, hs, variant, pos):
+    # [Wo + residual -> RMSNorm -> W1|W3 + SwiGLU] and [W2 + residual -> RMSNorm -> Wq|Wk|Wv + bias + RoPE +
+    # K/V placement], each as ONE launch, against the oracle's formulas step by step; and each single
+    # op through the same kernel
+    rng = np.random.default_rng(dim + hid + hs + pos)
+    m, v, sin, cos, ql, kl, S = _chain_case(rng, dim, hid, H, KVH, hs, variant, pos)
+    L = kx.lib()
+    dev = {k: (kx.Buf.from_numpy(a), kx.Buf.from_numpy(b)) for k, (a, b) in m.items()}
+    att, g1, g2, bias = (kx.Buf.from_numpy(v[k]) for k in ("att", "g1", "g2", "bias"))
+    x = kx.Buf.from_numpy(v["x"])
+    h, q = kx.Buf.zeros(hid), kx.Buf.zeros(ql)
+    kc, vc = kx.Buf.zeros(S * kl), kx.Buf.zeros(S * kl)
+    dsin, dcos = kx.Buf.from_numpy(sin), kx.Buf.from_numpy(cos)
+    pos_dev = kx.Buf.from_numpy(np.array([pos], np.int32))
+    ws = kx.Buf(L.kx_gemv_w8_chain_workspace_bytes(max(dim, hid)))
+    kx.check(L.kx_gemv_w8_chain_reset(ws.ptr, ws.nbytes, None), "reset")
+    wo = kx.make_gemv_desc(kx.GEMV_PLAIN, att.ptr, dev["wo"][0].ptr, dev["wo"][1].ptr, x.ptr, ql, dim, residual=x.ptr)
+    w13 = kx.make_gemv_desc(kx.GEMV_GATE_UP, None, dev["w13"][0].ptr, dev["w13"][1].ptr, h.ptr, dim, 2 * hid,
+                            norm_w=g1.ptr, norm_eps=1e-5)
+    w2 = kx.make_gemv_desc(kx.GEMV_PLAIN, h.ptr, dev["w2"][0].ptr, dev["w2"][1].ptr, x.ptr, hid, dim, residual=x.ptr)
+    qkv = kx.make_gemv_desc(kx.GEMV_QKV_ROPE, x.ptr, dev["qkv"][0].ptr, dev["qkv"][1].ptr, q.ptr, dim, ql + 2 * kl,
+                            norm_w=g2.ptr, norm_eps=1e-5, y1=kc.ptr, y2=vc.ptr, k0=ql, k1=ql + kl, bias=bias.ptr,
+                            sin=dsin.ptr, cos=dcos.ptr, pos_dev=pos_dev.ptr, rope_variant=variant, head_size=hs,
+                            kv_pos_stride=kl)
+    # oracle, in the reference's op order
+    x1 = kxo.gemv_w8(v["att"], *m["wo"], GS) + v["x"]
+    xn = kxo.rmsnorm(x1, v["g1"], 1e-5)
+    h13 = kxo.gemv_w8(xn, *m["w13"], GS)
+    hh = kxo.swiglu(h13[:hid], h13[hid:])
+    x2 = kxo.gemv_w8(hh, *m["w2"], GS) + x1
+    xn2 = kxo.rmsnorm(x2, v["g2"], 1e-5)
+    qkv_o = kxo.gemv_w8(xn2, *m["qkv"], GS) + v["bias"]
+    qo, ko, vo = qkv_o[:ql].copy(), qkv_o[ql:ql + kl].copy(), qkv_o[ql + kl:]
+    qo, ko = kxo.rope(variant, ql, kl, hs, qo, ko, pos, sin, cos)
+
+    def close(got, want, what):
+        assert np.abs(got - want).max() <= 3e-5 * max(1.0, np.abs(want).max()), what
+
+    for rep in range(2):   # twice: the second launch at the next position (new tags over the old granules)
+        kx.check(L.kx_memcpy_h2d(x.ptr, v["x"].ctypes.data, dim * 4, None), "h2d")
+        kx.check(L.kx_memcpy_h2d(pos_dev.ptr, np.array([pos + rep], np.int32).ctypes.data, 4, None), "h2d")
+        kx.gemv_chain([wo, w13], ws, chain_id=3, pos_dev=pos_dev.ptr)
+        close(x.numpy(), x1, "Wo + residual")
+        close(h.numpy(), hh, "W1|W3 + SwiGLU behind the seam")
+        if rep == 0:
+            kx.gemv_chain([w2, qkv], ws, chain_id=4, pos_dev=pos_dev.ptr)
+            close(x.numpy(), x2, "W2 + residual")
+            close(q.numpy(), qo, "q behind the seam")
+            close(kc.numpy().reshape(S, kl)[pos], ko, "k row")
+            close(vc.numpy().reshape(S, kl)[pos], vo, "v row")
+    gave = C.c_int32(0)
+    kx.check(L.kx_gemv_w8_chain_status(ws.ptr, C.byref(gave)), "status")
+    assert gave.value == 0
+    # one op alone through the same kernel (no seam)
+    kx.check(L.kx_memcpy_h2d(x.ptr, v["x"].ctypes.data, dim * 4, None), "h2d")
+    kx.gemv_chain([wo], ws, chain_id=9, pos=pos)
+    close(x.numpy(), x1, "single op")
