@@ -515,6 +515,11 @@ int kx_decode_step_end_candidates_embed(const float* candidates, int32_t ranks, 
  * [rows][cols] slice whose element (i, j) is element (row0+i, col0+j) of a global matrix with
  * leading dimension ld; the value depends only on (seed, global index), so tensor-parallel shards
  * are slices of one and the same tensor.  int8: uniform in [-127, 127]; f32: uniform in [lo, hi). */
+/* Reads `bytes` (rounded down to 16) at `ptr` with `workgroups` workgroups of 256 threads and
+ * keeps nothing: a prefetch of weights into the die-level cache, for a side stream that runs
+ * beside a latency-bound launch.  `sink` is one int the kernel never writes in practice (it keeps
+ * the loads alive).  No counterpart in the reference. */
+int kx_touch_bytes(const void* ptr, size_t bytes, int32_t workgroups, int32_t* sink, void* stream);
 int kx_fill_hash_i8(int8_t* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0, int64_t col0,
                     uint64_t seed, void* stream);
 int kx_fill_hash_f32(float* dst, int32_t rows, int32_t cols, int64_t ld, int64_t row0,

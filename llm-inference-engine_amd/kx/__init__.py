@@ -141,6 +141,7 @@ SIGNATURES = {
     "kx_argmax_candidate_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "kx_decode_step_end_candidates_embed": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "kx_decode_step_end_candidates": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "kx_touch_bytes": (C.c_int, [_vp, _sz, _i32, _vp, _vp]),
     "kx_fill_hash_i8": (C.c_int, [_vp, _i32, _i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _vp]),
     "kx_fill_hash_f32": (C.c_int, [_vp, _i32, _i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _f,
                                    _f, _vp]),
