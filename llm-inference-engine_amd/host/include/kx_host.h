@@ -46,6 +46,10 @@ int kxm_peer_disable(void* model);
 /* Row sub-blocks of the row-parallel prompt GEMMs under tensor parallelism: the all-reduce of one
  * sub-block runs on the side stream beside the GEMM of the next (1 = no overlap; default 4). */
 int kxm_set_prefill_subblocks(void* model, int32_t n);
+/* Policy of the fp16 weight images (TransformerConfig.prefill_weight_cache) changed on a live model:
+ * 0 gives kept images back.  kxm_weight_image_bytes: device memory the kept images hold now. */
+int kxm_set_prefill_weight_cache(void* model, int32_t policy);
+int kxm_weight_image_bytes(void* model, uint64_t* bytes);
 /* Test rig: tensor-parallel ranks as objects of one process (one host thread per rank), summing
  * through a host rendezvous instead of RCCL; eager launches only. */
 void* kxm_loopback_create(int32_t ranks);

@@ -120,6 +120,11 @@ class LlamaModel {
   // Row sub-blocks per row-parallel GEMM of a long prompt pass under tensor parallelism (>= 1;
   // 1 = one reduce after the whole GEMM, nothing overlapped).
   void set_prefill_subblocks(int32_t n) { prefill_subblocks_ = n < 1 ? 1 : n; }
+  // fp16 weight images of the long-prompt GEMMs: 0 made per pass in scratch, 1 kept, -1 kept if
+  // they fit a third of the free memory.  Kept images are given back when the policy turns to 0;
+  // the next long prompt decides again.
+  void set_prefill_weight_cache(int32_t policy);
+  size_t weight_image_bytes() const;
 
   // ---- reference-structured path ----
   base::Status forward_layers(int32_t token, int32_t pos, float* logits_host);

@@ -102,6 +102,18 @@ int kxm_peer_timed_out(void* m, int32_t* flag) {
   if (flag) *flag = f ? 1 : 0;
   return rc;
 }
+int kxm_set_prefill_weight_cache(void* m, int32_t policy) {
+  if (!m || policy < -1 || policy > 1) return -1;
+  M(m)->set_prefill_weight_cache(policy);
+  return 0;
+}
+
+int kxm_weight_image_bytes(void* m, uint64_t* bytes) {
+  if (!m || !bytes) return -1;
+  *bytes = M(m)->weight_image_bytes();
+  return 0;
+}
+
 int kxm_set_prefill_subblocks(void* m, int32_t n) {
   if (!m) return -1;
   M(m)->set_prefill_subblocks(n);

@@ -264,6 +264,22 @@ void LlamaModel::drop_weight_images(bool free_memory) {
   if (free_memory) weight_images_ = -1;
 }
 
+void LlamaModel::set_prefill_weight_cache(int32_t policy) {
+  cfg_.prefill_weight_cache = policy;
+  if (policy == 0) drop_weight_images(true);
+  weight_images_ = 0;  // decided again by the next long prompt
+  if (policy != 0)
+    for (auto& l : layers_)
+      if (l.qkv.w16) weight_images_ = 1;
+}
+
+size_t LlamaModel::weight_image_bytes() const {
+  size_t total = 0;
+  for (const auto& l : layers_)
+    for (const Linear* m : {&l.qkv, &l.wo, &l.w13, &l.w2}) total += m->w16_bytes;
+  return total;
+}
+
 base::Status LlamaModel::init_synthetic(uint64_t seed) {
   drop_weight_images(false);
   const TransformerConfig& c = cfg_;

@@ -183,6 +183,18 @@ class Model:
         hcheck(hlib().kxm_peer_timed_out(self.h, C.byref(f)), "kxm_peer_timed_out")
         return bool(f.value)
 
+    def set_prefill_weight_cache(self, policy):
+        L = hlib()
+        L.kxm_set_prefill_weight_cache.argtypes = [_vp, _i32]
+        hcheck(L.kxm_set_prefill_weight_cache(self.h, int(policy)), "kxm_set_prefill_weight_cache")
+
+    def weight_image_bytes(self):
+        L = hlib()
+        L.kxm_weight_image_bytes.argtypes = [_vp, C.POINTER(C.c_uint64)]
+        n = C.c_uint64(0)
+        hcheck(L.kxm_weight_image_bytes(self.h, C.byref(n)), "kxm_weight_image_bytes")
+        return n.value
+
     def set_prefill_subblocks(self, n):
         L = hlib()
         L.kxm_set_prefill_subblocks.argtypes = [_vp, _i32]

@@ -48,6 +48,12 @@ class Model:
     def set_prefill_subblocks(self, n):
         pass
 
+    def set_prefill_weight_cache(self, policy):
+        pass
+
+    def weight_image_bytes(self):
+        return 0
+
     def prefill(self, tokens, pos0=0, exact=False):
         time.sleep(0.002)
         self.tok, self.pos = 1, pos0 + len(tokens)
