@@ -161,8 +161,9 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 // PREFETCH: a wave with several tiles requests the next one before it consumes the current one
 // (costs a second set of tile registers; pointless when every wave has a single tile).
-// M4: the 4x4x1 form above (HS = 128, kv_mul <= 4).
-template <int HS, bool PREFETCH, typename KVT, bool M4 = false>
+// M4: the 4x4x1 form above (HS = 128) with M4 groups of four query heads: 1 for kv_mul <= 4, 2 for
+// kv_mul <= 8 (0: the 16-column form).
+template <int HS, bool PREFETCH, typename KVT, int M4 = 0>
 __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   __shared__ __attribute__((aligned(16))) float sm_o[kAttnWaves][16][HS];
   __shared__ float sm_sf[kAttnWaves * kMaxSplits];  // final merge: split weights, one set per wave
   __shared__ int sm_last;
-  __shared__ __attribute__((aligned(16))) float sm_p[M4 ? kAttnWaves * 64 : 4];  // M4: P of one tile per wave
+  __shared__ __attribute__((aligned(16))) float sm_p[M4 ? kAttnWaves * 64 * M4 : 4];  // M4: P of one tile per wave and head group
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -199,14 +200,20 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
 
   const int t_begin = cut.begin(split);
   const int t_end = t_begin + cut.count(split);
-  if constexpr (M4) {
-    static_assert(!M4 || HS == 128, "the 4x4x1 form is laid out for 128-wide heads");
+  if constexpr (M4 > 0) {
+    static_assert(M4 == 0 || HS == 128, "the 4x4x1 form is laid out for 128-wide heads");
+    // G groups of four query heads (kv_mul <= 4 G): every group repeats the two products on the
+    // tile the wave holds in registers, with its own Q fragment, softmax state and accumulators
+    constexpr int G = M4 > 0 ? M4 : 1;
     const int qd = lane >> 4, kb = (lane >> 2) & 3, hd = lane & 3, hi = lane >> 5;
     // Q: lane (qd, *, head hd) holds Q[head][16j + 4qd + e]; requested ahead of the tile
-    f32x4 qf4[8];
-    const float* qrow = q + ((size_t)kvh * kv_mul + min(hd, kv_mul - 1)) * HS + 4 * qd;
+    f32x4 qf4[G][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf4[j] = *KX_CKP(AB_Q, reinterpret_cast<const f32x4*>(qrow + 16 * j));
+    for (int gi = 0; gi < G; ++gi) {
+      const float* qrow = q + ((size_t)kvh * kv_mul + min(4 * gi + hd, kv_mul - 1)) * HS + 4 * qd;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf4[gi][j] = *KX_CKP(AB_Q, reinterpret_cast<const f32x4*>(qrow + 16 * j));
+    }
 
     int t = t_begin + wave;
     AttnTile4 cur;
@@ -214,11 +221,16 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
     // single-tile form: without the fences the scheduler sinks the tile loads into the product
     // loop and waits for them one at a time (the prefetching form schedules better without)
     if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
-    f32x4 o[4];  // o[t][r] = O[head r][dim 4(lane&31) + t], keys of parity hi
+    f32x4 o[G][4];  // o[gi][t][r] = O[head 4gi + r][dim 4(lane&31) + t], keys of parity hi
+    float m_run[G], l_run[G];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    float* pl = sm_p + wave * 64;
+    for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[gi][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      m_run[gi] = -INFINITY;
+      l_run[gi] = 0.f;
+    }
+    float* pl = sm_p + wave * 64 * G;
 
     for (; t < t_end; t += kAttnWaves) {
       const int key0 = t << 4;
@@ -226,57 +238,61 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       const bool more = t + kAttnWaves < t_end;
       if (PREFETCH && more)
         attn_load_tile4<KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
-      // ---- scores: rows = keys 4kb..4kb+3, columns = heads, this lane's quarter of the dims ----
-      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s0 = mfma4(cur.k[j].x, qf4[j].x, s0);
-        s1 = mfma4(cur.k[j].y, qf4[j].y, s1);
-        s0 = mfma4(cur.k[j].z, qf4[j].z, s0);
-        s1 = mfma4(cur.k[j].w, qf4[j].w, s1);
-      }
-      float sv[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+      for (int gi = 0; gi < G; ++gi) {
+        // ---- scores: rows = keys 4kb..4kb+3, columns = heads, this lane's quarter of the dims ----
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {  // sum of the four dim quarters
-        sv[r] = xor16_sum(sv[r]);
-        sv[r] = xor32_sum(sv[r]);
-        sv[r] *= scale;
-        if (key0 + 4 * kb + r > last) sv[r] = -INFINITY;
-      }
-      // every lane (any qd, kb) of head hd ends up with the head's maximum over the 16 keys
-      float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-      mx = fmaxf(mx, dpp_mov<0x124>(mx));  // row_ror:4 -> the next key block, same head
-      mx = fmaxf(mx, dpp_mov<0x128>(mx));  // row_ror:8
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp(m_run - m_new);  // first tile: exp(-inf) = 0
-      m_run = m_new;
-      float pv[4];
+        for (int j = 0; j < 8; ++j) {
+          s0 = mfma4(cur.k[j].x, qf4[gi][j].x, s0);
+          s1 = mfma4(cur.k[j].y, qf4[gi][j].y, s1);
+          s0 = mfma4(cur.k[j].z, qf4[gi][j].z, s0);
+          s1 = mfma4(cur.k[j].w, qf4[gi][j].w, s1);
+        }
+        float sv[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pv[r] = fast_exp(sv[r] - m_new);
-      l_run = l_run * alpha + ((pv[0] + pv[1]) + (pv[2] + pv[3]));  // this lane's 4 keys
-      // P[key][head] -> LDS as [parity][head][step], key = 2 step + parity, so that a lane of
-      // the second product reads the 8 probabilities it needs as two 16-byte words
-      if (qd == 0) {
+        for (int r = 0; r < 4; ++r) {  // sum of the four dim quarters
+          sv[r] = xor16_sum(sv[r]);
+          sv[r] = xor32_sum(sv[r]);
+          sv[r] *= scale;
+          if (key0 + 4 * kb + r > last) sv[r] = -INFINITY;
+        }
+        // every lane (any qd, kb) of head hd ends up with the head's maximum over the 16 keys
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        mx = fmaxf(mx, dpp_mov<0x124>(mx));  // row_ror:4 -> the next key block, same head
+        mx = fmaxf(mx, dpp_mov<0x128>(mx));  // row_ror:8
+        const float m_new = fmaxf(m_run[gi], mx);
+        const float alpha = fast_exp(m_run[gi] - m_new);  // first tile: exp(-inf) = 0
+        m_run[gi] = m_new;
+        float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pl[((r & 1) * 4 + hd) * 8 + 2 * kb + (r >> 1)] = pv[r];
-      }
-      // the accumulators keep the head on the register axis: alpha of head r for every lane
-      const float ah[4] = {dpp_mov<0x00>(alpha), dpp_mov<0x55>(alpha), dpp_mov<0xAA>(alpha),
-                           dpp_mov<0xFF>(alpha)};
+        for (int r = 0; r < 4; ++r) pv[r] = fast_exp(sv[r] - m_new);
+        l_run[gi] = l_run[gi] * alpha + ((pv[0] + pv[1]) + (pv[2] + pv[3]));  // this lane's 4 keys
+        // P[key][head] -> LDS as [parity][head][step], key = 2 step + parity, so that a lane of
+        // the second product reads the 8 probabilities it needs as two 16-byte words
+        float* plg = pl + 64 * gi;
+        if (qd == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e].x *= ah[0]; o[e].y *= ah[1]; o[e].z *= ah[2]; o[e].w *= ah[3];
-      }
-      const f32x4 pa0 = *reinterpret_cast<const f32x4*>(pl + (hi * 4 + hd) * 8);
-      const f32x4 pa1 = *reinterpret_cast<const f32x4*>(pl + (hi * 4 + hd) * 8 + 4);
-      const float pa[8] = {pa0.x, pa0.y, pa0.z, pa0.w, pa1.x, pa1.y, pa1.z, pa1.w};
-      // ---- output: rows = heads, columns = dims 4(lane&31) + t, one key per step ----
+          for (int r = 0; r < 4; ++r) plg[((r & 1) * 4 + hd) * 8 + 2 * kb + (r >> 1)] = pv[r];
+        }
+        // the accumulators keep the head on the register axis: alpha of head r for every lane
+        const float ah[4] = {dpp_mov<0x00>(alpha), dpp_mov<0x55>(alpha), dpp_mov<0xAA>(alpha),
+                             dpp_mov<0xFF>(alpha)};
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        o[0] = mfma4(pa[st], cur.v[st].x, o[0]);
-        o[1] = mfma4(pa[st], cur.v[st].y, o[1]);
-        o[2] = mfma4(pa[st], cur.v[st].z, o[2]);
-        o[3] = mfma4(pa[st], cur.v[st].w, o[3]);
+        for (int e = 0; e < 4; ++e) {
+          o[gi][e].x *= ah[0]; o[gi][e].y *= ah[1]; o[gi][e].z *= ah[2]; o[gi][e].w *= ah[3];
+        }
+        const f32x4 pa0 = *reinterpret_cast<const f32x4*>(plg + (hi * 4 + hd) * 8);
+        const f32x4 pa1 = *reinterpret_cast<const f32x4*>(plg + (hi * 4 + hd) * 8 + 4);
+        const float pa[8] = {pa0.x, pa0.y, pa0.z, pa0.w, pa1.x, pa1.y, pa1.z, pa1.w};
+        // ---- output: rows = heads, columns = dims 4(lane&31) + t, one key per step ----
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          o[gi][0] = mfma4(pa[st], cur.v[st].x, o[gi][0]);
+          o[gi][1] = mfma4(pa[st], cur.v[st].y, o[gi][1]);
+          o[gi][2] = mfma4(pa[st], cur.v[st].z, o[gi][2]);
+          o[gi][3] = mfma4(pa[st], cur.v[st].w, o[gi][3]);
+        }
       }
       if (more) {
         if (PREFETCH) cur = nxt;
@@ -285,25 +301,30 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
       if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- wave result -> LDS ----
-    l_run += dpp_mov<0x124>(l_run);  // the four key blocks of a head
-    l_run += dpp_mov<0x128>(l_run);
-    if (lane < 4 && lane < kv_mul) {
-      sm_m[wave][lane] = m_run;
-      sm_l[wave][lane] = l_run;
-    }
-    float oo[4][4];  // [head r][t], both key parities
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      oo[0][e] = xor32_sum(o[e].x);
-      oo[1][e] = xor32_sum(o[e].y);
-      oo[2][e] = xor32_sum(o[e].z);
-      oo[3][e] = xor32_sum(o[e].w);
-    }
-    if (lane < 32) {
+    for (int gi = 0; gi < G; ++gi) {
+      float lr = l_run[gi];
+      lr += dpp_mov<0x124>(lr);  // the four key blocks of a head
+      lr += dpp_mov<0x128>(lr);
+      if (lane < 4 && 4 * gi + lane < kv_mul) {
+        sm_m[wave][4 * gi + lane] = m_run[gi];
+        sm_l[wave][4 * gi + lane] = lr;
+      }
+      float oo[4][4];  // [head r][t], both key parities
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (r < kv_mul)
-          *reinterpret_cast<f32x4*>(&sm_o[wave][r][4 * lane]) = f32x4{oo[r][0], oo[r][1], oo[r][2], oo[r][3]};
+      for (int e = 0; e < 4; ++e) {
+        oo[0][e] = xor32_sum(o[gi][e].x);
+        oo[1][e] = xor32_sum(o[gi][e].y);
+        oo[2][e] = xor32_sum(o[gi][e].z);
+        oo[3][e] = xor32_sum(o[gi][e].w);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * gi + r < kv_mul)
+            *reinterpret_cast<f32x4*>(&sm_o[wave][4 * gi + r][4 * lane]) =
+                f32x4{oo[r][0], oo[r][1], oo[r][2], oo[r][3]};
+      }
     }
   } else {
   // Q fragment: B operand, lane (head n, group g) holds Q[head][16j+4g+e].  Lanes past the last
@@ -685,13 +706,20 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   } while (0)
   // up to four query heads per kv head: the 4x4x1 form of the matrix instruction (a quarter of
   // the matrix-core cycles of the 16-column form, which leaves 12 head columns idle)
-  const bool m4 = head_size == 128 && kv_mul <= 4;
+  // Five to eight heads run as two groups of four on the same tile registers only where that was
+  // measured faster than the 16-column form: eight heads per kv head (Llama-3-70B) from 2048 keys on
+  // (one kv head, 4368 keys: 13.8 vs 14.3 us; 1024 keys: 10.1 vs 9.8 us; seven heads -- Qwen2.5-7B,
+  // the second group one head short -- 16.6 vs 16.1 us at 4368 keys).  KX_ATTN_M4X2=1 / =0 force it.
+  int m4 = head_size != 128 ? 0 : kv_mul <= 4 ? 1 : (kv_mul == 8 && pos >= 2047) ? 2 : 0;
+  if (head_size == 128 && kv_mul > 4 && kv_mul <= 8)
+    if (const char* e = getenv("KX_ATTN_M4X2")) m4 = e[0] == '1' ? 2 : 0;
   switch (head_size) {
-    case 32: KX_ATTN_LAUNCH(32, false); break;
-    case 64: KX_ATTN_LAUNCH(64, false); break;
+    case 32: KX_ATTN_LAUNCH(32, 0); break;
+    case 64: KX_ATTN_LAUNCH(64, 0); break;
     case 128:
-      if (m4) KX_ATTN_LAUNCH(128, true);
-      else KX_ATTN_LAUNCH(128, false);
+      if (m4 == 1) KX_ATTN_LAUNCH(128, 1);
+      else if (m4 == 2) KX_ATTN_LAUNCH(128, 2);
+      else KX_ATTN_LAUNCH(128, 0);
       break;
     default: return KX_EUNSUPPORTED;
   }

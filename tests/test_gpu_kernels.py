@@ -226,7 +226,11 @@ def test_mha_decode_long_context_several_tiles_per_wave():
     # 128-wide heads with 1..4 query heads per kv head (the 4x4x1 matrix-instruction form): one kv
     # head as on a rank of an 8-way split, several tiles per wave, fewer than four heads
     (4, 1, 128, 4700, 4367), (4, 1, 128, 9100, 9000), (6, 2, 128, 2100, 2047), (2, 2, 128, 300, 257),
-    (3, 1, 128, 40, 33)])
+    (3, 1, 128, 40, 33),
+    # five to eight query heads per kv head: two groups of four on the same tile (Qwen2.5-7B: 28 / 4,
+    # Llama-3-70B: 64 / 8), single tiles, several tiles per wave, a last group that is not full
+    (28, 4, 128, 4700, 4367), (64, 8, 128, 4700, 4367), (8, 1, 128, 9100, 9000), (5, 1, 128, 300, 257),
+    (12, 2, 128, 2100, 2047), (7, 1, 128, 40, 15), (14, 2, 128, 8300, 8200)])
 def test_mha_decode_uneven_splits_past_two_workgroups_per_cu(H, KVH, hs, S, pos):
     # once one tile per wave would need more than two workgroups per CU the splits stop growing in
     # number: runs of near-equal length, the first `rem` one tile longer, some waves with two tiles
@@ -237,6 +241,24 @@ def test_mha_decode_uneven_splits_past_two_workgroups_per_cu(H, KVH, hs, S, pos)
     want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
     got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("H,KVH,hs,S,pos", [(28, 4, 128, 4700, 4367), (5, 1, 128, 300, 257), (12, 2, 128, 2100, 2047),
+                                            (7, 1, 128, 40, 15), (14, 2, 128, 8300, 8200), (8, 1, 128, 700, 640)])
+def test_mha_decode_two_head_groups_forced(H, KVH, hs, S, pos, monkeypatch):
+    # the two-groups-of-four form is picked by itself only for eight heads per kv head on long
+    # contexts; forced here for five to eight heads, short and long, last group not full
+    monkeypatch.setenv("KX_ATTN_M4X2", "1")
+    rng = np.random.default_rng(pos + H)
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    monkeypatch.setenv("KX_ATTN_M4X2", "0")
+    same = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(same, want, rtol=0, atol=2e-5)
 
 
 def test_mha_decode_device_position_grid_for_a_longer_context():
