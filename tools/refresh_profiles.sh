@@ -38,3 +38,4 @@ timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES S
 cd $R
 python tools/collect_mfma.py $O/pmc_mfma/m_counter_collection.csv $O/prefill_mfma.json > /dev/null
 rm -rf $O/pmc_mfma
+python tools/summarise_refresh.py $O
