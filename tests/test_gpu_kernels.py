@@ -1358,3 +1358,56 @@ def test_gemv_chain_vs_oracle(dim, hid, H, KVH, hs, variant, pos):
     kx.check(L.kx_memcpy_h2d(x.ptr, v["x"].ctypes.data, dim * 4, None), "h2d")
     kx.gemv_chain([wo], ws, chain_id=9, pos=pos)
     close(x.numpy(), x1, "single op")
+
+
+def test_gemv_chain_refuses_what_it_cannot_run():
+    # argument checks of the chained launch: every refusal is a return code, nothing is launched
+    L = kx.lib()
+    rng = np.random.default_rng(1)
+    M, K = 1024, 64
+    w = kx.Buf.from_numpy(rng.integers(-127, 128, (K, M), dtype=np.int8))
+    s_ = kx.Buf.from_numpy(np.ones(K * M // GS, np.float32))
+    x, y = kx.Buf.zeros(M), kx.Buf.zeros(K)
+    ws = kx.Buf(L.kx_gemv_w8_chain_workspace_bytes(1024))
+    kx.check(L.kx_gemv_w8_chain_reset(ws.ptr, ws.nbytes, None), "reset")
+
+    def run(descs, chain_id=0, pos=0, wsb=None):
+        arr = (kx.GemvDesc * len(descs))(*descs)
+        return L.kx_gemv_w8_chain_f32(arr, len(descs), ws.ptr, ws.nbytes if wsb is None else wsb, chain_id, None, pos, None)
+
+    good = kx.make_gemv_desc(kx.GEMV_PLAIN, x.ptr, w.ptr, s_.ptr, y.ptr, M, K)
+    assert run([good]) == 0
+    kx.sync()
+    assert run([good], chain_id=128) != 0 and run([good], pos=-1) != 0
+    assert run([kx.make_gemv_desc(kx.GEMV_PLAIN, x.ptr, w.ptr, s_.ptr, y.ptr, M, K, group_size=32)]) != 0
+    assert run([kx.make_gemv_desc(kx.GEMV_PLAIN, x.ptr, w.ptr, s_.ptr, y.ptr, 512, K)]) != 0       # M % 1024
+    assert run([kx.make_gemv_desc(kx.GEMV_PLAIN, x.ptr, w.ptr, s_.ptr, y.ptr, M, 60)]) != 0        # K % 8
+    assert run([kx.make_gemv_desc(kx.GEMV_PLAIN, None, w.ptr, s_.ptr, y.ptr, M, K)]) != 0          # no input
+    # a second op whose width is not the first op's row count; a workspace too small for the seam
+    y2 = kx.Buf.zeros(K)
+    second = kx.make_gemv_desc(kx.GEMV_PLAIN, None, w.ptr, s_.ptr, y2.ptr, M, K)
+    assert run([good, second]) != 0                                                              # 64 outputs, 1024 wide
+    w2 = kx.Buf.from_numpy(rng.integers(-127, 128, (1024, M), dtype=np.int8))
+    s2 = kx.Buf.from_numpy(np.ones(1024 * M // GS, np.float32))
+    y1k = kx.Buf.zeros(1024)
+    first = kx.make_gemv_desc(kx.GEMV_PLAIN, x.ptr, w2.ptr, s2.ptr, y1k.ptr, M, 1024)
+    assert run([first, second], wsb=256 + 8 * 512) != 0
+    assert run([first, second]) == 0
+    kx.sync()
+    gave = C.c_int32(1)
+    kx.check(L.kx_gemv_w8_chain_status(ws.ptr, C.byref(gave)), "status")
+    assert gave.value == 0
+
+
+def test_touch_bytes_reads_and_keeps_nothing():
+    L = kx.lib()
+    a = np.arange(1 << 20, dtype=np.int32)
+    b = kx.Buf.from_numpy(a)
+    sink = kx.Buf.zeros(1, np.int32)
+    for n in (0, 15, 16, 4096 + 48, a.nbytes):
+        kx.check(L.kx_touch_bytes(b.ptr, n, 64, sink.ptr, None), "kx_touch_bytes")
+    kx.sync()
+    np.testing.assert_array_equal(b.numpy(), a)
+    assert sink.numpy()[0] == 0
+    assert L.kx_touch_bytes(b.ptr + 4, 64, 64, sink.ptr, None) != 0      # 16-byte alignment
+    assert L.kx_touch_bytes(b.ptr, 64, 0, sink.ptr, None) != 0

@@ -484,6 +484,31 @@ def test_kept_fp16_weight_images_give_the_same_prompt_results():
     assert np.abs(outs[1][1] - outs[1][4]).max() > 0
 
 
+def test_weight_image_policy_changed_on_a_live_model():
+    # set_prefill_weight_cache on a model that already holds images: policy 0 gives them back
+    # (weight_image_bytes() == 0) and the next prompt de-quantises per pass; back to "kept" the
+    # images are made again; every pass gives the bit-identical result (same kernels, same images)
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    rng = np.random.default_rng(9)
+    p = rng.integers(0, 1000, 600).astype(np.int32)
+    m = host.Model(seq_len=640, group_size=GS, prefill_weight_cache=1, **shape)
+    m.init_synthetic(31)
+    assert m.weight_image_bytes() == 0          # nothing before the first long prompt
+    kept = m.prefill(p)
+    per_layer = 2 * (512 * (512 + 2 * 128) + 512 * 512 + 2 * 1024 * 512 + 512 * 1024)
+    assert m.weight_image_bytes() >= 2 * per_layer
+    m.set_prefill_weight_cache(0)
+    assert m.weight_image_bytes() == 0
+    np.testing.assert_array_equal(m.prefill(p), kept)
+    assert m.weight_image_bytes() == 0
+    m.set_prefill_weight_cache(-1)              # kept if they fit: they do
+    np.testing.assert_array_equal(m.prefill(p), kept)
+    assert m.weight_image_bytes() >= 2 * per_layer
+    np.testing.assert_array_equal(m.prefill(p), kept)   # second pass on the kept images
+    m.close()
+
+
 def test_prompts_up_to_192_rows_stream_the_int8_weights(monkeypatch):
     # up to 192 rows the prompt pass runs the few-rows kernel on the int8 weights (no fp16 image, with
     # or without prefill_weight_cache, whatever came before): within the batched-prompt tolerance of
