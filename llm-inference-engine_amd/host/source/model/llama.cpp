@@ -1021,7 +1021,30 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   // Batched prompt: rows go through the MFMA GEMMs and the flash-attention kernel in chunks.
   void* st = hip_->stream;
   const int32_t ql = c.q_dim_local, kl = c.kv_dim_local, hl = c.hidden_local, dim = c.dim;
-  const int32_t chunk = n < kPrefillChunk ? n : kPrefillChunk;
+  int32_t chunk = n < kPrefillChunk ? n : kPrefillChunk;
+  {
+    // A prompt of 193..384 rows on a model WITHOUT fp16 weight images (policy 0, or images that do
+    // not fit) runs as two pieces of at most 192 rows through the few-rows kernel, which streams the
+    // int8 weights once per piece (Llama-3-8B: 224 / 256 / 320 / 384 rows in 10.6 / 10.9 / 12.6 /
+    // 13.9 ms against 18.5 / 18.9 / 21.4 / 22.2 ms for the int8 single-pass kernel those lengths got
+    // before).  Three pieces (448 rows: 18.1 ms) lose to converting the weights per pass and running
+    // the fp16 GEMMs (512 rows: 16.9 ms), which therefore starts at 385 rows; with kept images the
+    // fp16 GEMMs win from 193 rows.
+    const int gs0 = c.group_size;
+    const bool attn16 = c.head_size == 32 || c.head_size == 64 || c.head_size == 128;
+    const bool rows_ok = gs0 == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 && attn16 &&
+                         getenv("KX_PREFILL_NO_ROWS_KERNEL") == nullptr && getenv("KX_PREFILL_ROWS_MAX") == nullptr;
+    const bool f16_shapes = (gs0 & (gs0 - 1)) == 0 && gs0 >= 16 && dim % 64 == 0 && ql % 64 == 0 && hl % 64 == 0 &&
+                            dim % gs0 == 0 && ql % gs0 == 0 && hl % gs0 == 0 && attn16;
+    if (rows_ok && n > 192 && n <= 384 && getenv("KX_PREFILL_NO_PIECES") == nullptr) {
+      if (f16_shapes) ST_RET(reserve_weight_images());  // the decision a 193+ row prompt makes anyway
+      if (weight_images_ != 1) {
+        const int32_t pieces = (n + 191) / 192;
+        chunk = ((n + pieces - 1) / pieces + 15) / 16 * 16;
+        if (chunk > 192) chunk = 192;
+      }
+    }
+  }
   // scratch: X, XN [chunk][dim]; Q, ATT [chunk][ql]; H13 [chunk][2hl]; HH [chunk][hl]; then the
   // fp16 workspace of the two-pass GEMM, sized for the widest matrix of a layer
   // with a 16-bit cache the K/V rows of a chunk pass through fp32 scratch (RoPE runs there) and
@@ -1122,7 +1145,7 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     const bool rows_fused = few_rows && !env_unfused;
     const bool rows_fused_rope = rows_fused && ql % 128 == 0 && kl % 128 == 0;
     if (!few_rows && f16_ok && rows >= 32) ST_RET(reserve_weight_images());
-    int32_t f16_min_rows = weight_images_ == 1 ? 32 : 512;
+    int32_t f16_min_rows = weight_images_ == 1 ? 32 : 385;
     if (env_f16_min) f16_min_rows = atoi(env_f16_min);
     const bool f16_chunk = !few_rows && f16_ok && rows >= f16_min_rows;
     for (int32_t l = 0; l < c.layer_num; ++l) {

@@ -556,6 +556,40 @@ def test_prompts_up_to_192_rows_stream_the_int8_weights(monkeypatch):
         x.close()
 
 
+def test_prompts_of_193_to_384_rows_without_weight_images_run_as_pieces(monkeypatch):
+    # no fp16 images (policy 0): a prompt of 193..384 rows is cut into two pieces of at most
+    # 192 rows, each through the few-rows kernel on the int8 weights, later pieces attending the
+    # earlier ones' cache rows.  Within the batched-prompt tolerance of one fp32 decode step per row,
+    # K/V rows included; the single-pass int8 kernel (pieces switched off) stays within it too; with
+    # kept images the same prompts take the fp16 GEMMs and the policy setter moves between the two
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=2, vocab_size=1000,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    rng = np.random.default_rng(14)
+    m = host.Model(seq_len=640, group_size=GS, prefill_weight_cache=0, **shape)
+    m.init_synthetic(31)
+    ref = host.Model(seq_len=640, group_size=GS, **shape)
+    ref.init_synthetic(31)
+    for n in (193, 256, 300, 384, 385, 448):  # 385+: weights converted per pass, fp16 GEMMs
+        p = rng.integers(0, 1000, n).astype(np.int32)
+        got = m.prefill(p)
+        assert m.weight_image_bytes() == 0
+        want = ref.prefill(p, exact=True)
+        assert np.abs(got - want).max() <= 4e-3 * np.abs(want).max(), n
+        for layer in range(2):
+            k, v = m.read_kv(layer, n)
+            kr, vr = ref.read_kv(layer, n)
+            assert np.abs(k - kr).max() <= 4e-3 * np.abs(kr).max(), (n, layer)
+            assert np.abs(v - vr).max() <= 4e-3 * np.abs(vr).max(), (n, layer)
+        assert m.state()[1] == n
+        np.testing.assert_array_equal(m.prefill(p), got)           # repeatable
+        monkeypatch.setenv("KX_PREFILL_NO_PIECES", "1")
+        whole = m.prefill(p)                                        # the int8 single-pass kernel on all rows
+        monkeypatch.delenv("KX_PREFILL_NO_PIECES")
+        assert np.abs(whole - want).max() <= 4e-3 * np.abs(want).max(), n
+    for x in (m, ref):
+        x.close()
+
+
 def test_short_prompts_with_qkv_biases_and_interleaved_rope():
     # the few-rows prompt pass with q / k / v biases (Qwen2's layout) ahead of the rotation, for both
     # RoPE variants: against one fp32 decode step per row, K/V rows included
