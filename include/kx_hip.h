@@ -47,6 +47,9 @@ int kx_get_device(int* device);
 int kx_device_name(char* buf, size_t buf_bytes);
 int kx_malloc(void** ptr, size_t bytes);
 int kx_free(void* ptr);
+/* stream == NULL: the fill is complete when the call returns (the library's streams are
+ * non-blocking: they do not wait for work queued on the null stream).  With a stream it is
+ * ordered on that stream like a kernel. */
 int kx_memset(void* ptr, int value, size_t bytes, void* stream);
 int kx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream); /* stream NULL: blocking */
 int kx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);

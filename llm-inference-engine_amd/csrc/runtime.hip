@@ -151,6 +151,11 @@ extern "C" int kx_memset(void* ptr, int value, size_t bytes, void* stream) {
   if (!ptr && bytes) return KX_EINVAL;
   if (bytes == 0) return KX_OK;
   KX_HIP_TRY(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
+  // Without a stream the fill has happened when the call returns.  The streams of this library
+  // are created non-blocking, so nothing orders work on them behind a fill that is still queued on
+  // the null stream: a kernel that writes the buffer next (rotary tables, synthetic weights, the
+  // first K/V rows) could otherwise run ahead of the fill and have its output zeroed afterwards.
+  if (!stream) KX_HIP_TRY(hipStreamSynchronize(nullptr));
   return KX_OK;
 }
 

@@ -102,6 +102,39 @@ def test_prompt_pass_with_a_head_size_the_fp16_attention_has_no_form_for():
         ref.close()
 
 
+def test_model_created_while_the_null_stream_is_busy():
+    # The model's buffers are zero-filled without a stream and first written by kernels on the
+    # model's own NON-BLOCKING stream (rotary tables, synthetic weights).  A fill still pending on
+    # the null stream when those kernels ran zeroed their output afterwards: 3 of 11 runs of this
+    # suite against the bounds-checking build had one model whose rotary table began with zeros (K
+    # row 0 all zero in the fused loop, logits off by 1-2 % from step 1 on).  kx_memset without a
+    # stream now completes before it returns.  This case creates and fills a model while the null
+    # stream is busy; it guards the ordering, though the pending fill of the original failure came
+    # from the runtime's own batching and did not need a busy stream.
+    shape = dict(dim=512, hidden_dim=832, layer_num=2, head_num=4, kv_head_num=2, vocab_size=1243,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-6)
+    L = kx.lib()
+    ref = host.Model(seq_len=256, group_size=GS, **shape)
+    ref.init_synthetic(77)
+    big = kx.Buf(1 << 30)
+    for rep in range(200):    # ~0.3 ms each at 1 GiB: the null stream stays busy through the creation below
+        kx.check(L.kx_fill_hash_f32(big.ptr, 1, 1 << 28, 1 << 28, 0, 0, rep, -1.0, 1.0, None), "fill")
+    m = host.Model(seq_len=256, group_size=GS, **shape)
+    for rep in range(200):
+        kx.check(L.kx_fill_hash_f32(big.ptr, 1, 1 << 28, 1 << 28, 0, 0, rep, -1.0, 1.0, None), "fill")
+    m.init_synthetic(77)
+    rng = np.random.default_rng(3)
+    for p, t in enumerate(rng.integers(0, 1243, 4)):
+        a, b = m.step_logits(int(t), p), ref.forward_layers(int(t), p)
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), p
+    prompt = rng.integers(0, 1243, 14).astype(np.int32)
+    got, want = m.prefill(prompt), ref.prefill(prompt, exact=True)
+    assert np.abs(got - want).max() <= 6e-3 * np.abs(want).max()
+    m.close()
+    ref.close()
+    big.free()
+
+
 def test_randomised_kernel_sweep_fixed_seed():
     import fuzz_parity
     assert fuzz_parity.run(40, 20261) == 0

@@ -56,6 +56,21 @@ def run(N=12, seed=3, head_sizes=(32, 64, 128)):
                 if not np.abs(a - b).max() <= tol * np.abs(b).max():
                     bad += 1
                     print(f"MISMATCH step {p}: {np.abs(a - b).max() / np.abs(b).max():.2e} {case}", flush=True)
+                    # the same step again on both models: a result that changes names the path that
+                    # is not repeatable (a race, or memory read before it was written)
+                    a2, b2 = m.step_logits(int(t), p), ref.forward_layers(int(t), p)
+                    sc = np.abs(b2).max()
+                    print(f"  again: fused loop moved {np.abs(a2 - a).max() / sc:.2e}, layer loop moved "
+                          f"{np.abs(b2 - b).max() / sc:.2e}, now apart {np.abs(a2 - b2).max() / sc:.2e}; "
+                          f"worst element {int(np.argmax(np.abs(a - b)))} of {a.size}: {a[np.argmax(np.abs(a - b))]:.5f} vs "
+                          f"{b[np.argmax(np.abs(a - b))]:.5f}, elements off {(np.abs(a - b) > tol * np.abs(b).max()).sum()}", flush=True)
+                    # where the two caches part: K rows that differ while V rows agree point at the
+                    # rotation (tables, position), both at the projections, neither at the attention
+                    for layer in range(shape["layer_num"]):
+                        (k1, v1), (k2, v2) = m.read_kv(layer, p + 1), ref.read_kv(layer, p + 1)
+                        print(f"  layer {layer}: K rows apart {[float(f'{x:.1e}') for x in np.abs(k1 - k2).max(1) / np.abs(k2).max()]}"
+                              f" V rows apart {[float(f'{x:.1e}') for x in np.abs(v1 - v2).max(1) / np.abs(v2).max()]}"
+                              f" |K| fused {[float(f'{x:.2e}') for x in np.abs(k1).max(1)]} layer loop {[float(f'{x:.2e}') for x in np.abs(k2).max(1)]}", flush=True)
                     break
             for n in (int(rng.integers(2, 65)), int(rng.integers(65, 193)), int(rng.integers(193, seq - 3)), seq - 3):
                 prompt = rng.integers(0, shape["vocab_size"], n).astype(np.int32)
