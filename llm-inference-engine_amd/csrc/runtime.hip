@@ -166,6 +166,9 @@ static int copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, vo
     KX_HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream));
   } else {
     KX_HIP_TRY(hipMemcpy(dst, src, bytes, kind));
+    // a device-to-device hipMemcpy may return before the copy has run; without a stream every
+    // transfer of this library is complete on return (see kx_memset)
+    if (kind == hipMemcpyDeviceToDevice) KX_HIP_TRY(hipStreamSynchronize(nullptr));
   }
   return KX_OK;
 }
