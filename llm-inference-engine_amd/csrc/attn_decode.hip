@@ -27,7 +27,7 @@ namespace kx {
 // operands of the bounds-checking build
 enum AttnOperand { AB_Q, AB_K, AB_V, AB_OUT, AB_WS, AB_TICKETS, AB_POS };
 
-constexpr int kAttnWaves = 4;
+constexpr int kAttnWaves = 4;      // waves per workgroup (the eight-wave form below: NW = 8)
 constexpr int kMaxSplits = 128;
 // Head of the workspace: one arrival ticket per kv head.  Zero before the first launch; every
 // launch leaves the tickets at zero again (atomicInc wraps at the launch's split count).
@@ -41,7 +41,7 @@ __host__ __device__ inline size_t attn_ws_stride(int hs) { return (size_t)hs + 4
 
 // Split geometry shared by host and device.  The ntiles 16-key tiles of a kv head are cut into
 // nsplit contiguous runs whose lengths differ by at most one (the first `rem` runs hold one tile
-// more); never more splits than ceil(ntiles / kAttnWaves), so no wave of a split is idle unless
+// more); never more splits than ceil(ntiles / nw) for workgroups of nw waves, so no wave of a split is idle unless
 // the whole context is shorter than that.
 struct AttnSplit {
   int nsplit, base, rem;
@@ -54,8 +54,9 @@ struct AttnSplit {
 // workgroup per CU: with waves walking several tiles anyway, 256 workgroups of 8+ tiles beat 512 of
 // 4..5 (equal at 4.4k keys, 1.5 % of a token at 8k).
 // (fp32 cache only: with 16-bit rows a tile is half the bytes and the finer cut stays ahead.)
-__host__ __device__ inline AttnSplit attn_split(int ntiles, int grid_splits, int kvh, bool fp32_cache) {
-  int ns = (ntiles + kAttnWaves - 1) / kAttnWaves;
+__host__ __device__ inline AttnSplit attn_split(int ntiles, int grid_splits, int kvh, bool fp32_cache,
+                                                int nw = kAttnWaves) {
+  int ns = (ntiles + nw - 1) / nw;
   if (ns > grid_splits && !fp32_cache) ns = grid_splits;
   if (ns > grid_splits) {
     const int one_per_cu = 256 / kvh > 0 ? 256 / kvh : 1;
@@ -163,8 +164,11 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // (costs a second set of tile registers; pointless when every wave has a single tile).
 // M4: the 4x4x1 form above (HS = 128) with M4 groups of four query heads: 1 for kv_mul <= 4, 2 for
 // kv_mul <= 8 (0: the 16-column form).
-template <int HS, bool PREFETCH, typename KVT, int M4 = 0>
-__global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
+// NW: waves per workgroup.  8 (one workgroup per CU; 4x4x1 forms only, whose per-wave results are
+// small enough for LDS) halves the number of splits a long context is cut into at the same number
+// of waves in flight: half the partials to publish, acknowledge and merge behind the stream.
+template <int HS, bool PREFETCH, typename KVT, int M4 = 0, int NW = kAttnWaves>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
     const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale,
@@ -178,9 +182,12 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   stamp(0);
   constexpr int NJ = AttnTile<HS>::NJ;  // float4 K loads per lane per tile
   constexpr int NH = AttnTile<HS>::NH;  // 64-dim halves of the output
+  constexpr int kAttnWaves = NW;  // (shadows the default: everything below is per NW)
+  constexpr int MAXH = M4 ? 4 * M4 : 16;  // query heads of a kv head this form can hold
+  static_assert(NW == 4 || (NW == 8 && M4 > 0), "eight waves: 4x4x1 forms only");
   __shared__ float sm_m[kAttnWaves][16];
   __shared__ float sm_l[kAttnWaves][16];
-  __shared__ __attribute__((aligned(16))) float sm_o[kAttnWaves][16][HS];
+  __shared__ __attribute__((aligned(16))) float sm_o[kAttnWaves][MAXH][HS];
   __shared__ float sm_sf[kAttnWaves * kMaxSplits];  // final merge: split weights, one set per wave
   __shared__ int sm_last;
   __shared__ __attribute__((aligned(16))) float sm_p[M4 ? kAttnWaves * 64 * M4 : 4];  // M4: P of one tile per wave and head group
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 2) void attn_decode_kernel(
   // the grid is then sized for the longest context and surplus splits leave at once.
   const int last = pos_dev ? *KX_CKP(AB_POS, pos_dev) : last_val;
   const int ntiles = (last >> 4) + 1;
-  const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x, sizeof(KVT) == 4);
+  const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x, sizeof(KVT) == 4, NW);
   const int nsplit = cut.nsplit;
   if (split >= nsplit) return;
   const KVT* kbase = kc + (size_t)kvh * HS;
@@ -664,8 +671,26 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // both requested up front by the PREFETCH form): a CU that draws a third workgroup finishes
   // late, and so does a kv head whose split count runs into a third merge pass -- 69 splits of 4
   // tiles cost 15.3 us at 4368 keys where 64 splits of 4..5 cost 14.2.
-  int nsplit = (ntiles + kAttnWaves - 1) / kAttnWaves;
-  const int cap_grid = 512 / kvh > 0 ? 512 / kvh : 1;
+  // up to four query heads per kv head: the 4x4x1 form of the matrix instruction (a quarter of
+  // the matrix-core cycles of the 16-column form, which leaves 12 head columns idle)
+  // Five to eight heads run as two groups of four on the same tile registers only where that was
+  // measured faster than the 16-column form: eight heads per kv head (Llama-3-70B) from 2048 keys on
+  // (one kv head, 4368 keys: 13.8 vs 14.3 us; 1024 keys: 10.1 vs 9.8 us; seven heads -- Qwen2.5-7B,
+  // the second group one head short -- 16.6 vs 16.1 us at 4368 keys).  KX_ATTN_M4X2=1 / =0 force it.
+  int m4 = head_size != 128 ? 0 : kv_mul <= 4 ? 1 : (kv_mul == 8 && pos >= 2047) ? 2 : 0;
+  if (head_size == 128 && kv_mul > 4 && kv_mul <= 8)
+    if (const char* e = getenv("KX_ATTN_M4X2")) m4 = e[0] == '1' ? 2 : 0;
+  // Eight waves per workgroup, one workgroup per CU (4x4x1 forms): chosen where the four-wave form
+  // has run out of its finest cut (one tile per wave in two workgroups per CU) and would fall back
+  // to one four-wave workgroup per CU with 8+ tiles per split.  Twice the waves in flight per split
+  // there: Llama-3-8B geometry at 4368 keys 12.7 vs 13.1 us, equal at 8192; below that point the
+  // four-wave form wins (4096 keys: 12.4 vs 12.6 us; 2048: 8.7 vs 10.2).  KX_ATTN_NW=4 / =8 force
+  // a form (8: 4x4x1 forms only).
+  const int one_per_cu = 256 / kvh > 0 ? 256 / kvh : 1;
+  int nw = m4 > 0 && (ntiles + kAttnWaves - 1) / kAttnWaves > 2 * one_per_cu ? 8 : kAttnWaves;
+  if (const char* e = getenv("KX_ATTN_NW")) nw = (e[0] == '8' && m4 > 0) ? 8 : kAttnWaves;
+  int nsplit = (ntiles + nw - 1) / nw;
+  const int cap_grid = nw == 8 ? one_per_cu : (512 / kvh > 0 ? 512 / kvh : 1);
   if (nsplit > cap_grid) nsplit = cap_grid;
   if (nsplit > kMaxSplits) nsplit = kMaxSplits;
   if (kvh > kMaxTickets) return KX_EUNSUPPORTED;
@@ -678,12 +703,12 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // The grid keeps the two-per-CU split count even where the cut at `pos` falls back to one per CU:
   // a launch that reads its position from the device may see shorter contexts, for which the
   // finer cut is the better one (surplus workgroups leave at once).
-  const AttnSplit cut = attn_split(ntiles, nsplit, kvh, kFp32Cache);
+  const AttnSplit cut = attn_split(ntiles, nsplit, kvh, kFp32Cache, nw);
   if (!pos_dev) nsplit = cut.nsplit;
   unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
   float* ws = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes) : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(kvh, nsplit), block(kAttnWaves * 64);
+  const dim3 grid(kvh, nsplit), block(nw * 64);
   // KX_ATTN_TRACE set and a workspace with room behind the partials: per-workgroup timeline there
   unsigned long long* trace = nullptr;
   {
@@ -692,38 +717,33 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
     if (env_trace && workspace && workspace_bytes >= used + (size_t)kvh * nsplit * 64)
       trace = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + used);
   }
-  const bool prefetch = cut.longest() > kAttnWaves;
-#define KX_ATTN_LAUNCH(HS_, M4_)                                                                 \
+  const bool prefetch = cut.longest() > nw;
+#define KX_ATTN_LAUNCH_NW(HS_, M4_, NW_)                                                          \
   do {                                                                                           \
     if (prefetch)                                                                                \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_, NW_>), grid, block, 0, s, query, kc, vc, \
                          out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace             \
                          KX_BPASS(7, query, kc, vc, out, ws, tickets, pos_dev));                        \
     else                                                                                         \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_>), grid, block, 0, s, query, kc, vc, \
+      hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_, NW_>), grid, block, 0, s, query, kc, vc, \
                          out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace             \
                          KX_BPASS(7, query, kc, vc, out, ws, tickets, pos_dev));                        \
   } while (0)
-  // up to four query heads per kv head: the 4x4x1 form of the matrix instruction (a quarter of
-  // the matrix-core cycles of the 16-column form, which leaves 12 head columns idle)
-  // Five to eight heads run as two groups of four on the same tile registers only where that was
-  // measured faster than the 16-column form: eight heads per kv head (Llama-3-70B) from 2048 keys on
-  // (one kv head, 4368 keys: 13.8 vs 14.3 us; 1024 keys: 10.1 vs 9.8 us; seven heads -- Qwen2.5-7B,
-  // the second group one head short -- 16.6 vs 16.1 us at 4368 keys).  KX_ATTN_M4X2=1 / =0 force it.
-  int m4 = head_size != 128 ? 0 : kv_mul <= 4 ? 1 : (kv_mul == 8 && pos >= 2047) ? 2 : 0;
-  if (head_size == 128 && kv_mul > 4 && kv_mul <= 8)
-    if (const char* e = getenv("KX_ATTN_M4X2")) m4 = e[0] == '1' ? 2 : 0;
+#define KX_ATTN_LAUNCH(HS_, M4_) KX_ATTN_LAUNCH_NW(HS_, M4_, 4)
   switch (head_size) {
     case 32: KX_ATTN_LAUNCH(32, 0); break;
     case 64: KX_ATTN_LAUNCH(64, 0); break;
     case 128:
-      if (m4 == 1) KX_ATTN_LAUNCH(128, 1);
+      if (m4 == 1 && nw == 8) KX_ATTN_LAUNCH_NW(128, 1, 8);
+      else if (m4 == 2 && nw == 8) KX_ATTN_LAUNCH_NW(128, 2, 8);
+      else if (m4 == 1) KX_ATTN_LAUNCH(128, 1);
       else if (m4 == 2) KX_ATTN_LAUNCH(128, 2);
       else KX_ATTN_LAUNCH(128, 0);
       break;
     default: return KX_EUNSUPPORTED;
   }
 #undef KX_ATTN_LAUNCH
+#undef KX_ATTN_LAUNCH_NW
   KX_LAUNCH_CHECK();
   return KX_OK;
 }

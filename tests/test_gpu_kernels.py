@@ -261,6 +261,34 @@ def test_mha_decode_two_head_groups_forced(H, KVH, hs, S, pos, monkeypatch):
     np.testing.assert_allclose(same, want, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("H,KVH,hs,S,pos", [(32, 8, 128, 4700, 4367), (4, 1, 128, 300, 257), (6, 2, 128, 2100, 2047),
+                                            (3, 1, 128, 40, 15), (8, 1, 128, 9100, 9000), (16, 4, 128, 700, 640)])
+def test_mha_decode_eight_wave_workgroups_forced(H, KVH, hs, S, pos, monkeypatch):
+    # eight waves per workgroup (one workgroup per CU) is picked by itself only past the finest cut
+    # of the four-wave form; forced here on short and long contexts, one and two head groups, and
+    # through the device-position entry with a grid sized for a longer context
+    monkeypatch.setenv("KX_ATTN_NW", "8")
+    monkeypatch.setenv("KX_ATTN_M4X2", "1")
+    rng = np.random.default_rng(pos * 3 + H)
+    kc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    vc = rng.standard_normal((1, S, KVH * hs)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    want = kxo.mha(pos, H, 0, S, KVH * hs, H // KVH, hs, q, kc, vc).reshape(H, hs)
+    got = kx.mha_decode(q, kc, vc, pos, H, H // KVH, hs, 0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    L = kx.lib()
+    dq, dk, dv = (kx.Buf.from_numpy(a) for a in (q, kc, vc))
+    out = kx.Buf.zeros(H * hs)
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    pos_dev = kx.Buf.from_numpy(np.array([pos], np.int32))
+    for _ in range(2):   # the tickets are back at zero after a launch
+        kx.check(L.kx_mha_decode_dpos_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H, H // KVH, hs,
+                                          KVH * hs, S, 0, ws.ptr, wsb, None), "dpos")
+        np.testing.assert_allclose(out.numpy().reshape(H, hs), want, rtol=0, atol=2e-5)
+    assert not ws.numpy()[:16384].any()
+
+
 def test_mha_decode_device_position_grid_for_a_longer_context():
     # graph-replay form with the grid cut for 4736 rows (64 splits of 4..5 tiles at the end) and
     # positions on both sides of the point where the first split gets its fifth tile
