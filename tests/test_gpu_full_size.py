@@ -130,6 +130,60 @@ def test_fused_qkv_rope_model_size_vs_oracle(dim, H, KVH, hs, theta, eps, bias, 
 
 
 # ---- flash attention at full prompt sizes ----------------------------------------------------------
+def test_gemv_chain_llama3_8b_layer_shapes():
+    # the two chains of a decode step as ONE launch each, at Llama-3-8B layer shapes (the opt-in
+    # kx_gemv_w8_chain_f32): [Wo + residual -> RMSNorm -> W1|W3 + SwiGLU] and [W2 + residual ->
+    # RMSNorm -> Wq|Wk|Wv + RoPE + K/V placement], every output against the oracle's step-by-step
+    # formulas (fp32 FMA chains: 3e-5 of the vector's range)
+    rng = np.random.default_rng(88)
+    dim, hid, H, KVH, hs, pos = 4096, 14336, 32, 8, 128, 4100
+    ql, kl, S = H * hs, KVH * hs, pos + 2
+    L = kx.lib()
+
+    def w8(K, M):
+        return rng.integers(-127, 128, (K, M), dtype=np.int8), rng.uniform(1e-4, 3e-4, K * M // GS).astype(np.float32)
+    m = dict(wo=w8(dim, ql), w13=w8(2 * hid, dim), w2=w8(dim, hid), qkv=w8(ql + 2 * kl, dim))
+    att, x0 = rng.standard_normal(ql).astype(np.float32), rng.standard_normal(dim).astype(np.float32)
+    g1, g2 = (rng.uniform(0.5, 1.5, dim).astype(np.float32) for _ in range(2))
+    sin, cos = kxo.sin_cos_cache(hs, S, 5e5)
+    dev = {k: (kx.Buf.from_numpy(a), kx.Buf.from_numpy(b)) for k, (a, b) in m.items()}
+    datt, dg1, dg2, x = (kx.Buf.from_numpy(a) for a in (att, g1, g2, x0))
+    h, q = kx.Buf.zeros(hid), kx.Buf.zeros(ql)
+    kc, vc = kx.Buf.zeros(S * kl), kx.Buf.zeros(S * kl)
+    dsin, dcos = kx.Buf.from_numpy(sin), kx.Buf.from_numpy(cos)
+    pos_dev = kx.Buf.from_numpy(np.array([pos], np.int32))
+    ws = kx.Buf(L.kx_gemv_w8_chain_workspace_bytes(hid))
+    kx.check(L.kx_gemv_w8_chain_reset(ws.ptr, ws.nbytes, None), "reset")
+    wo = kx.make_gemv_desc(kx.GEMV_PLAIN, datt.ptr, dev["wo"][0].ptr, dev["wo"][1].ptr, x.ptr, ql, dim, residual=x.ptr)
+    w13 = kx.make_gemv_desc(kx.GEMV_GATE_UP, None, dev["w13"][0].ptr, dev["w13"][1].ptr, h.ptr, dim, 2 * hid,
+                            norm_w=dg1.ptr, norm_eps=1e-5)
+    w2 = kx.make_gemv_desc(kx.GEMV_PLAIN, h.ptr, dev["w2"][0].ptr, dev["w2"][1].ptr, x.ptr, hid, dim, residual=x.ptr)
+    qkv = kx.make_gemv_desc(kx.GEMV_QKV_ROPE, None, dev["qkv"][0].ptr, dev["qkv"][1].ptr, q.ptr, dim, ql + 2 * kl,
+                            norm_w=dg2.ptr, norm_eps=1e-5, y1=kc.ptr, y2=vc.ptr, k0=ql, k1=ql + kl, sin=dsin.ptr,
+                            cos=dcos.ptr, pos_dev=pos_dev.ptr, rope_variant=1, head_size=hs, kv_pos_stride=kl)
+    x1 = kxo.gemv_w8(att, *m["wo"], GS, threads=8) + x0
+    h13 = kxo.gemv_w8(kxo.rmsnorm(x1, g1, 1e-5), *m["w13"], GS, threads=8)
+    hh = kxo.swiglu(h13[:hid], h13[hid:])
+    x2 = kxo.gemv_w8(hh, *m["w2"], GS, threads=8) + x1
+    qkv_o = kxo.gemv_w8(kxo.rmsnorm(x2, g2, 1e-5), *m["qkv"], GS, threads=8)
+    qo, ko = kxo.rope(1, ql, kl, hs, qkv_o[:ql].copy(), qkv_o[ql:ql + kl].copy(), pos, sin, cos)
+
+    def close(got, want, what):
+        assert np.abs(got - want).max() <= 3e-5 * max(1.0, np.abs(want).max()), what
+    kx.gemv_chain([wo, w13], ws, chain_id=1, pos_dev=pos_dev.ptr)
+    close(x.numpy(), x1, "Wo + residual")
+    close(h.numpy(), hh, "W1|W3 + SwiGLU behind the seam")
+    kx.gemv_chain([w2, qkv], ws, chain_id=2, pos_dev=pos_dev.ptr)
+    close(x.numpy(), x2, "W2 + residual")
+    close(q.numpy(), qo, "q behind the seam")
+    close(kc.numpy().reshape(S, kl)[pos], ko, "k row")
+    close(vc.numpy().reshape(S, kl)[pos], qkv_o[ql + kl:], "v row")
+    assert not kc.numpy().reshape(S, kl)[:pos].any() and not vc.numpy().reshape(S, kl)[pos + 1:].any()
+    gave = C.c_int32(1)
+    kx.check(L.kx_gemv_w8_chain_status(ws.ptr, C.byref(gave)), "status")
+    assert gave.value == 0
+
+
 @pytest.mark.parametrize("H,KVH,hs,Tq,what", [
     (32, 8, 128, 4096, "Llama-3-8B, 4096-row prompt"), (8, 1, 128, 8192, "70B rank at TP=8, 8192 rows"),
     (32, 8, 64, 4096, "Llama-3.2-1B"), (28, 4, 128, 4096, "Qwen2.5-7B"),
