@@ -104,7 +104,64 @@ def run(N=40, seed=1):
         ref = kxo.mha(p_, H, 0, S, KVH * hs, H // KVH, hs, qd, kc, vc).reshape(H, hs)
         report("mha_decode", (H, KVH, hs, p_), np.abs(one - ref), 1e-4 * np.ones_like(ref))
 
-    print(f"{7 * N} kernel runs checked, {bad} mismatches", flush=True)
+    # ---- two GEMVs in one launch (kx_gemv_w8_chain_f32): [plain + residual -> RMSNorm -> gate|up +
+    # SwiGLU] and [plain + residual -> RMSNorm -> q|k|v + bias + RoPE + K/V placement] ----
+    L = kx.lib()
+    for _ in range(max(1, N // 4)):
+        hs = int(rng.choice([32, 64, 128]))
+        KVH = int(rng.choice([1, 2, 4]))
+        H = KVH * int(rng.choice([1, 2, 4]))
+        dim = 1024 * int(rng.integers(1, 4))
+        hid = 1024 * int(rng.integers(1, 4))
+        ql, kl = H * hs, KVH * hs
+        if ql % 1024 or (ql + 2 * kl) % 8:
+            ql = 1024                           # the first op's input width must be whole 1024-column steps
+            H = ql // hs
+            KVH = min(KVH, H)
+            H = H // KVH * KVH
+            ql, kl = H * hs, KVH * hs
+            if ql % 1024:
+                continue
+        variant, pos = int(rng.integers(0, 2)), int(rng.integers(0, 50))
+        S = pos + 2
+        mats = dict(wo=w8(dim, ql, 1e-4, 3e-3), w13=w8(2 * hid, dim, 1e-4, 3e-3), w2=w8(dim, hid, 1e-4, 3e-3),
+                    qkv=w8(ql + 2 * kl, dim, 1e-4, 3e-3))
+        att, x0 = rng.standard_normal(ql).astype(np.float32), rng.standard_normal(dim).astype(np.float32)
+        g1, g2 = (rng.uniform(0.5, 1.5, dim).astype(np.float32) for _ in range(2))
+        bias = (rng.standard_normal(ql + 2 * kl) * 0.1).astype(np.float32)
+        sin, cos = kxo.sin_cos_cache(hs, S, 1e4)
+        dev = {k: (kx.Buf.from_numpy(a_), kx.Buf.from_numpy(b_)) for k, (a_, b_) in mats.items()}
+        datt, dg1, dg2, dbias, x = (kx.Buf.from_numpy(a_) for a_ in (att, g1, g2, bias, x0))
+        h, q = kx.Buf.zeros(hid), kx.Buf.zeros(ql)
+        kc, vc = kx.Buf.zeros(S * kl), kx.Buf.zeros(S * kl)
+        dsin, dcos = kx.Buf.from_numpy(sin), kx.Buf.from_numpy(cos)
+        ws = kx.Buf(L.kx_gemv_w8_chain_workspace_bytes(max(dim, hid)))
+        kx.check(L.kx_gemv_w8_chain_reset(ws.ptr, ws.nbytes, None), "reset")
+        d_wo = kx.make_gemv_desc(kx.GEMV_PLAIN, datt.ptr, dev["wo"][0].ptr, dev["wo"][1].ptr, x.ptr, ql, dim, residual=x.ptr)
+        d_w13 = kx.make_gemv_desc(kx.GEMV_GATE_UP, None, dev["w13"][0].ptr, dev["w13"][1].ptr, h.ptr, dim, 2 * hid,
+                                  norm_w=dg1.ptr, norm_eps=1e-5)
+        d_w2 = kx.make_gemv_desc(kx.GEMV_PLAIN, h.ptr, dev["w2"][0].ptr, dev["w2"][1].ptr, x.ptr, hid, dim, residual=x.ptr)
+        d_qkv = kx.make_gemv_desc(kx.GEMV_QKV_ROPE, None, dev["qkv"][0].ptr, dev["qkv"][1].ptr, q.ptr, dim, ql + 2 * kl,
+                                  norm_w=dg2.ptr, norm_eps=1e-5, y1=kc.ptr, y2=vc.ptr, k0=ql, k1=ql + kl, bias=dbias.ptr,
+                                  sin=dsin.ptr, cos=dcos.ptr, pos=pos, rope_variant=variant, head_size=hs, kv_pos_stride=kl)
+        x1 = kxo.gemv_w8(att, *mats["wo"], GS) + x0
+        h13 = kxo.gemv_w8(kxo.rmsnorm(x1, g1, 1e-5), *mats["w13"], GS)
+        hh = kxo.swiglu(h13[:hid], h13[hid:])
+        x2 = kxo.gemv_w8(hh, *mats["w2"], GS) + x1
+        qkv_o = kxo.gemv_w8(kxo.rmsnorm(x2, g2, 1e-5), *mats["qkv"], GS) + bias
+        qo, ko = kxo.rope(variant, ql, kl, hs, qkv_o[:ql].copy(), qkv_o[ql:ql + kl].copy(), pos, sin, cos)
+        case = (dim, hid, H, KVH, hs, variant, pos)
+        kx.gemv_chain([d_wo, d_w13], ws, chain_id=int(rng.integers(0, 128)), pos=pos)
+        report("chain Wo", case, np.abs(x.numpy() - x1), 3e-5 * max(1.0, np.abs(x1).max()) * np.ones_like(x1))
+        report("chain W1|W3", case, np.abs(h.numpy() - hh), 3e-5 * max(1.0, np.abs(hh).max()) * np.ones_like(hh))
+        kx.gemv_chain([d_w2, d_qkv], ws, chain_id=int(rng.integers(0, 128)), pos=pos)
+        report("chain W2", case, np.abs(x.numpy() - x2), 3e-5 * max(1.0, np.abs(x2).max()) * np.ones_like(x2))
+        report("chain q", case, np.abs(q.numpy() - qo), 3e-5 * max(1.0, np.abs(qo).max()) * np.ones_like(qo))
+        report("chain k", case, np.abs(kc.numpy().reshape(S, kl)[pos] - ko), 3e-5 * max(1.0, np.abs(ko).max()) * np.ones_like(ko))
+        report("chain v", case, np.abs(vc.numpy().reshape(S, kl)[pos] - qkv_o[ql + kl:]),
+               3e-5 * max(1.0, np.abs(qkv_o).max()) * np.ones(kl))
+
+    print(f"{7 * N} kernel runs (+ {max(1, N // 4)} chained launches) checked, {bad} mismatches", flush=True)
     return bad
 
 
