@@ -753,6 +753,45 @@ def test_tensor_parallel_prompt_sub_blocks_equal_single_rank():
     one.close()
 
 
+def test_tensor_parallel_prompts_under_both_weight_image_policies():
+    # the sequence bench.py runs on every rank at N > 1: policy 0 (no fp16 image kept), prompt,
+    # policy -1, prompt, prompt -- on two ranks of this process; every pass agrees across the ranks
+    # and with the unsharded model, for a long prompt (per-pass conversion / kept images) and for one
+    # of 300 rows (two few-rows pieces without images, fp16 GEMMs with them)
+    shape = dict(dim=512, hidden_dim=1024, layer_num=2, head_num=8, kv_head_num=4, vocab_size=700,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    rng = np.random.default_rng(16)
+    one = host.Model(seq_len=1200, group_size=GS, **shape)
+    one.init_synthetic(21)
+    group = host.loopback_create(2)
+    ranks = [host.Model(seq_len=1200, group_size=GS, tp_size=2, tp_rank=r, **shape) for r in range(2)]
+    for m in ranks:
+        m.init_synthetic(21)
+        m.join_loopback(group)
+    for n in (1100, 300):
+        toks = rng.integers(0, 700, n).astype(np.int32)
+        want = one.prefill(toks)
+
+        def passes(r, m):
+            out = []
+            m.set_prefill_weight_cache(0)
+            out.append(m.prefill(toks))
+            assert m.weight_image_bytes() == 0
+            m.set_prefill_weight_cache(-1)
+            out.append(m.prefill(toks))
+            out.append(m.prefill(toks))
+            assert m.weight_image_bytes() > 0
+            return out
+        got = _run_ranks(ranks, passes)
+        for a_, b_ in zip(got[0], got[1]):
+            np.testing.assert_array_equal(a_, b_)
+            assert np.abs(a_ - want).max() <= 4e-3 * np.abs(want).max(), n
+    for m in ranks:
+        m.close()
+    host.loopback_destroy(group)
+    one.close()
+
+
 # ---------------- 16-bit KV cache -------------------------------------------------------------------
 @pytest.mark.parametrize("n", [40, 530])
 def test_kv16_model_tracks_the_fp32_cache_model(n):
