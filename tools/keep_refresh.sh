@@ -1,8 +1,8 @@
 #!/bin/bash
-# keep_refresh.sh RNN: copies the summaries of gpurun_out/refresh/ (tools/refresh_profiles.sh) that
-# are kept under version control into profiles/ as rNN_*
+# keep_refresh.sh PREFIX: copies the summaries of gpurun_out/refresh/ (tools/refresh_profiles.sh) that
+# are kept under version control into profiles/ as PREFIX_*
 set -e
-R=${1:-r02}; O=gpurun_out/refresh; P=profiles
+R=${1:?usage: keep_refresh.sh PREFIX}; O=gpurun_out/refresh; P=profiles
 cp $O/bench.json $P/${R}_bench_line.json
 cp $O/prof/b_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
 cp $O/traffic.json $P/${R}_gemv_traffic.json

@@ -2,12 +2,12 @@
 # Runs on the GPU box (from the repository root): the headline bench line, the micro-benchmarks,
 # the other model shapes, rocprofv3 kernel statistics of the bench command and the two PMC
 # passes for the GEMV's HBM traffic.  Results land under gpurun_out/refresh/; the summaries that
-# are kept are copied into profiles/ by tools/keep_refresh.sh.  refresh_profiles.sh [rNN]
+# are kept are copied into profiles/ by tools/keep_refresh.sh.  refresh_profiles.sh PREFIX
 # The two PMC passes come FIRST and their result is put where bench.py looks for it
-# (profiles/rNN_gemv_traffic.json, on the box), so that every bench line of this refresh carries
+# (profiles/PREFIX_gemv_traffic.json, on the box), so that every bench line of this refresh carries
 # the traffic figure of the kernel source it ran.
 set -e
-RN=${1:-r03}
+RN=${1:?usage: refresh_profiles.sh PREFIX (the kept files become profiles/PREFIX_*)}
 R=$(pwd); O=$R/gpurun_out/refresh; mkdir -p $O
 B="--no-cpu-baseline --no-prefill-kernels"
 cd /tmp && export TMPDIR=/tmp
