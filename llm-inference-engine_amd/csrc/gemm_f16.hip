@@ -40,6 +40,9 @@ struct GemmF16Args {
   float* slabs;
   unsigned* tickets;
   int32_t full_tiles, split;
+  // the parts only write their slabs; gemm_split_combine_kernel, launched behind this one, adds
+  // them and writes the tiles (plain / residual form, reductions cut four ways or more)
+  int32_t combine_later;
   int32_t wide_rows;  // every destination row is 16-byte aligned: the epilogue may use 16-byte accesses
   // Wq|Wk|Wv form (pipelined kernel, wide rows): bias (all K columns, or null), then the rotary
   // embedding of the q columns [0, k0) and the k columns [k0, k1) at position pos0 + row
@@ -605,6 +608,15 @@ __device__ __forceinline__ void gp_combine(const GemmF16Args& a, const char* sla
   }
 }
 
+// first row and column of tile `wgid` in the order the workgroups walk the tiles
+__device__ __forceinline__ void gp_tile_origin(const GemmF16Args& a, int wgid, int& t0, int& n0) {
+  const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
+  const int panel = wgid / (tiles_m * GP_GROUP_N), local = wgid - panel * (tiles_m * GP_GROUP_N);
+  const int gn = min(GP_GROUP_N, tiles_n - panel * GP_GROUP_N);
+  t0 = (local / gn) * 256;
+  n0 = (panel * GP_GROUP_N + local % gn) * 256;
+}
+
 template <bool SWIGLU, bool ROPE = false, bool SHORT = false>
 __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -613,7 +625,6 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   const int wr = wave >> 2, wc = wave & 3;
   // workgroups that share an XCD (ids equal mod 8) take consecutive tiles, walking down the token
   // dimension first: they share W column panels through that XCD's L2
-  const int tiles_m = (a.T + 255) / 256;
   // two classes of workgroups, whole tiles first: each class is dealt over the XCDs on its own,
   // so every XCD gets the same share of both
   const bool whole = (int)blockIdx.x < a.full_tiles;
@@ -627,10 +638,8 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   // inside that sequence, panels of GP_GROUP_N column tiles are walked column-first: the ~32
   // workgroups an XCD runs at a time then cover about 8 x 4 tiles and share 12 operand panels
   // instead of 18
-  const int tiles_n = (a.K + 255) / 256;
-  const int panel = wgid / (tiles_m * GP_GROUP_N), local = wgid - panel * (tiles_m * GP_GROUP_N);
-  const int gn = min(GP_GROUP_N, tiles_n - panel * GP_GROUP_N);
-  const int t0 = (local / gn) * 256, n0 = (panel * GP_GROUP_N + local % gn) * 256;
+  int t0, n0;
+  gp_tile_origin(a, wgid, t0, n0);
 
   GemmPipeCtx c;
   // this workgroup's share of the reduction: K-tiles [kt0, kt0 + c.nt)
@@ -722,6 +731,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + (mi * 4 + ni) * 1024, 0, 16);
       }
     }
+    if (a.combine_later) return;  // the kernel boundary publishes the slabs; the combine launch does the rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // also: every wave is past its last read of the K-tile buffers
     int* flag = reinterpret_cast<int*>(smem);
@@ -759,6 +769,117 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
   }
 }
 
+// The sum of a cut reduction spread over the chip.  With four parts or more the last arriver of a
+// tile read S x 256 KiB of slabs alone -- one workgroup fetching 1-4 MiB at the 60-70 GB/s a
+// workgroup gets from other CUs' fresh stores: 20-40 us behind a main loop of 10-15 (Wo of
+// Llama-3-8B at 256 rows: 59 us, of which the matrix work is a fifth).  Here one WAVE takes one
+// 16-row block of one wave tile (16 x 64 outputs): 1024 waves for 16 tiles, each adding S x 4 KiB
+// in part order (the same sum whatever finished first), turning its block round in 4 KiB of LDS
+// into whole 256-byte row segments, and writing it with the plain epilogue's row factor, routing
+// and residual -- or (ROPE) the Wq|Wk|Wv form's bias, rotary embedding and K/V row placement: the
+// four waves of a workgroup hold four neighbouring 64-column blocks of one row block, so the
+// half-split partner of a 128-wide head is the neighbouring wave's image, as in the GEMM's own
+// epilogue.  Launched behind the GEMM whose parts only wrote their slabs.
+template <int S, bool ROPE>
+__global__ __launch_bounds__(256) void gemm_split_combine_kernel(const GemmF16Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[4][1024];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wv;              // (tile of the partial round, row block, wave position)
+  const int r = unit >> 6, mi = (unit >> 3) & 7, wpos = unit & 7;
+  const int wgid = a.full_tiles + r;
+  int t0, n0;
+  gp_tile_origin(a, wgid, t0, n0);
+  const int wr = wpos >> 2, wc = wpos & 3;
+  const int trow0 = t0 + wr * 128 + mi * 16, ncol0 = n0 + wc * 64;
+  if (trow0 >= a.T) return;                          // a block of padding rows: never stored
+  const int c16 = lane & 15, g = lane >> 4;
+  const char* slab_base = reinterpret_cast<const char*>(a.slabs + (size_t)r * S * 65536);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(slab_base), 0, (unsigned)S * 262144u, 0x00020000);
+  const unsigned lane_off = (unsigned)(wpos * 32 * 1024 + mi * 4 * 1024 + lane * 16);
+  float* wb = lds[wv];
+  constexpr int NIB = S <= 8 ? 4 : 2;  // column blocks whose loads are in flight together (32 loads per lane)
+#pragma unroll
+  for (int nb = 0; nb < 4; nb += NIB) {
+    u32x4 v[NIB][S];
+#pragma unroll
+    for (int j = 0; j < NIB; ++j)
+#pragma unroll
+      for (int pp = 0; pp < S; ++pp) {
+        const unsigned off = (unsigned)pp * 262144u + lane_off + (nb + j) * 1024;
+        KX_TOUCH(a, FB_SLABS, slab_base + off, 16);
+        v[j][pp] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      }
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+      const int ni = nb + j;
+      f32x4 t = {__uint_as_float(v[j][0].x), __uint_as_float(v[j][0].y), __uint_as_float(v[j][0].z),
+                 __uint_as_float(v[j][0].w)};
+#pragma unroll
+      for (int pp = 1; pp < S; ++pp) {
+        t[0] += __uint_as_float(v[j][pp].x); t[1] += __uint_as_float(v[j][pp].y);
+        t[2] += __uint_as_float(v[j][pp].z); t[3] += __uint_as_float(v[j][pp].w);
+      }
+      const int n = ncol0 + ni * 16 + c16;
+      const float f = n < a.K ? *KX_CK(a, FB_COLF, a.colf + n) : 0.f;
+      const float bias = ROPE && a.bias && n < a.K ? *KX_CK(a, FB_BIAS, a.bias + n) : 0.f;
+      // lane (column c16 of block ni, row group g) holds rows 4g .. 4g+3: the epilogue's LDS image
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) wb[(4 * g + rr) * 64 + ((ni * 16 + c16) ^ (16 * g))] = t[rr] * f + bias;
+    }
+  }
+  if (ROPE) __syncthreads();  // the neighbouring wave's image is read below (uniform: one row block per workgroup)
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave reads back what its own lanes wrote
+  const int n4 = ncol0 + 4 * c16;
+  float* dst;
+  int64_t ld;
+  int col;
+  [[maybe_unused]] int op;
+  bool add_res = false;
+  if (n4 < a.k0) {
+    dst = a.y0; ld = a.ld0; col = n4; add_res = a.residual != nullptr; op = FB_Y0;
+  } else if (n4 < a.k1) {
+    dst = a.y1; ld = a.ld1; col = n4 - a.k0; op = FB_Y1;
+  } else {
+    dst = a.y2; ld = a.ld2; col = n4 - a.k1; op = FB_Y2;
+  }
+  // rotary embedding as in gemm_pipe_epilogue_lds (rope_kernel.cu:5-36 half split, :98-128 interleaved)
+  const bool turn = ROPE && a.rope_variant >= 0 && n4 < a.k1;
+  const int hsz = ROPE ? a.head_size : 1;
+  const int d = col % hsz;
+  const bool hsplit = a.rope_variant == KX_ROPE_HALF_SPLIT;
+  const int hhalf = hsz >> 1;
+  const bool low = d < hhalf;
+  const int tab = hsplit ? 2 * (low ? d : d - hhalf) : d;
+  const float* pb = hsz == 128 ? lds[wv ^ 1] : wb;
+  const int pcol = hsz == 128 ? 4 * c16 : (4 * c16) ^ 32;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 4 + g, t = trow0 + row;
+    const int sw = 16 * ((row >> 2) & 3);
+    f32x4 o = *reinterpret_cast<const f32x4*>(wb + row * 64 + ((4 * c16) ^ sw));
+    if (turn) {
+      const size_t trow = (size_t)(a.pos0 + min(t, a.T - 1)) * a.head_size + tab;
+      if (hsplit) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(pb + row * 64 + (pcol ^ sw));
+        const f32x4 s0 = *KX_CK(a, FB_SIN, reinterpret_cast<const f32x4*>(a.sin_cache + trow));
+        const f32x4 s1 = *KX_CK(a, FB_SIN, reinterpret_cast<const f32x4*>(a.sin_cache + trow + 4));
+        const f32x4 c0 = *KX_CK(a, FB_COS, reinterpret_cast<const f32x4*>(a.cos_cache + trow));
+        const f32x4 c1 = *KX_CK(a, FB_COS, reinterpret_cast<const f32x4*>(a.cos_cache + trow + 4));
+        const f32x4 sn = {s0.x, s0.z, s1.x, s1.z}, cs = {c0.x, c0.z, c1.x, c1.z};
+        o = low ? o * cs - pv * sn : pv * sn + o * cs;
+      } else {
+        const f32x4 s0 = *KX_CK(a, FB_SIN, reinterpret_cast<const f32x4*>(a.sin_cache + trow));
+        const f32x4 c0 = *KX_CK(a, FB_COS, reinterpret_cast<const f32x4*>(a.cos_cache + trow));
+        o = f32x4{o.x * c0.x - o.y * s0.x, o.x * s0.x + o.y * c0.x, o.z * c0.z - o.w * s0.z, o.z * s0.z + o.w * c0.z};
+      }
+    }
+    if (t < a.T && n4 < a.K) {
+      if (add_res) o += *KX_CK(a, FB_RES, reinterpret_cast<const f32x4*>(a.residual + (size_t)t * a.ldr + col));
+      *KX_CK(a, op, reinterpret_cast<f32x4*>(dst + (size_t)t * ld + col)) = o;
+    }
+  }
+}
+
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_swiglu_kernel(const GemmF16Args a) { gemm_f16_pipe_body<true>(a); }
 __global__ __launch_bounds__(512, 1) void gemm_f16_pipe_qkv_rope_kernel(const GemmF16Args a) { gemm_f16_pipe_body<false, true>(a); }
@@ -778,7 +899,10 @@ constexpr int kPipeCUs = 256;
 // ways takes ceil(R S / 256) rounds of nt / S steps, plus the slabs' way through memory -- every
 // part writes its live rows (256 KiB for a full tile) and the last arriver reads them all back,
 // ~0.16 per full slab with the whole chip doing it at once.
-static int pipe_split_choice(int tiles, int nt, int T, size_t split_ws_bytes) {
+// later: the sum of four parts or more runs as a launch of its own over the whole chip
+// (gemm_split_combine_kernel): about 0.125 per slab plus a launch, fitted on Wo / Wq|Wk|Wv / W2 of
+// Llama-3-8B at 256-512 rows.
+static int pipe_split_choice(int tiles, int nt, int T, size_t split_ws_bytes, bool later = false) {
   const int R = tiles % kPipeCUs;
   if (R == 0 || split_ws_bytes <= kSplitTicketBytes) return 1;
   const size_t slabs_fit = (split_ws_bytes - kSplitTicketBytes) / kSplitSlabBytes;
@@ -787,7 +911,8 @@ static int pipe_split_choice(int tiles, int nt, int T, size_t split_ws_bytes) {
   double best_cost = 1.45 * nt + 4.0;
   for (int S = 2; S <= 16; S *= 2) {
     if (nt < 8 * S || (size_t)R * S > slabs_fit || R > (int)(kSplitTicketBytes / 4)) continue;
-    const double cost = (double)((R * S + kPipeCUs - 1) / kPipeCUs) * (1.45 * nt / S + 4.0) + 0.16 * live * R * S;
+    const double sum_cost = later && S >= 4 ? 0.125 * live * R * S + 1.0 : 0.16 * live * R * S;
+    const double cost = (double)((R * S + kPipeCUs - 1) / kPipeCUs) * (1.45 * nt / S + 4.0) + sum_cost;
     if (cost < 0.95 * best_cost) {
       best_cost = cost;
       best = S;
@@ -796,23 +921,16 @@ static int pipe_split_choice(int tiles, int nt, int T, size_t split_ws_bytes) {
   return best;
 }
 
+// plain: the kernel has the plain / residual epilogue; rope: the Wq|Wk|Wv epilogue -- the two forms
+// the separate combine launch knows (SwiGLU keeps its sum with the last arriver)
 template <void (*KERN)(GemmF16Args)>
 static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_bytes, hipStream_t s,
-                                bool need_wide = false) {
+                                bool need_wide = false, bool plain = false, bool rope = false) {
   const int tiles_m = (a.T + 255) / 256, tiles_n = (a.K + 255) / 256;
   const int tiles = tiles_m * tiles_n;
   // 128 KiB of dynamic LDS needs the opt-in, once per kernel and device
   static OncePerDevice opted_in;  // one instance per kernel
   if (int rc = opted_in.raise(reinterpret_cast<const void*>(KERN), 2 * GP_BUF)) return rc;
-  int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, a.T, split_ws_bytes) : 1;
-  if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
-    const int want = atoi(e);
-    const size_t need = kSplitTicketBytes + (size_t)(tiles % kPipeCUs) * want * kSplitSlabBytes;
-    if (want == 1 || ((want == 2 || want == 4 || want == 8 || want == 16) && split_ws && split_ws_bytes >= need &&
-                      a.M / GF_BK >= 2 * want && tiles % kPipeCUs && tiles % kPipeCUs <= 1024))
-      split = want;
-  }
-  a.split = split;
   {
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool swiglu = a.h16 != nullptr;
@@ -823,13 +941,43 @@ static int launch_gemm_f16_pipe(GemmF16Args a, void* split_ws, size_t split_ws_b
     if (getenv("KX_GEMM_NARROW_EPILOGUE") && !need_wide) a.wide_rows = 0;  // A/B runs and tests
     if (need_wide && !a.wide_rows) return KX_EUNSUPPORTED;
   }
+  // four parts or more of a plain or Wq|Wk|Wv product: the sum runs as a launch of its own, spread
+  // over the chip (KX_GEMM_COMBINE=0 keeps it with the last arriver, for A/B runs and tests)
+  const char* combine_env = getenv("KX_GEMM_COMBINE");
+  const bool later = (plain || rope) && a.wide_rows && !(combine_env && combine_env[0] == '0');
+  int split = split_ws ? pipe_split_choice(tiles, a.M / GF_BK, a.T, split_ws_bytes, later) : 1;
+  if (const char* e = getenv("KX_GEMM_SPLIT")) {  // A/B runs and tests: 1, 2, 4, 8 or 16
+    const int want = atoi(e);
+    const size_t need = kSplitTicketBytes + (size_t)(tiles % kPipeCUs) * want * kSplitSlabBytes;
+    if (want == 1 || ((want == 2 || want == 4 || want == 8 || want == 16) && split_ws && split_ws_bytes >= need &&
+                      a.M / GF_BK >= 2 * want && tiles % kPipeCUs && tiles % kPipeCUs <= 1024))
+      split = want;
+  }
+  a.split = split;
   a.full_tiles = split > 1 ? tiles - tiles % kPipeCUs : tiles;
   a.tickets = static_cast<unsigned*>(split_ws);
   a.slabs = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitTicketBytes);
   const int grid = a.full_tiles + (tiles - a.full_tiles) * split;
+  a.combine_later = later && split >= 4;
   KX_BSET(a, FB_SLABS, split_ws ? a.slabs : nullptr); KX_BSET(a, FB_TICKETS, a.tickets);
   hipLaunchKernelGGL(KERN, dim3(grid), dim3(512), 2 * GP_BUF, s, a);
   KX_LAUNCH_CHECK();
+  if (a.combine_later) {
+    const int units = (tiles - a.full_tiles) * 64;  // (tile, wave position, 16-row block), one wave each
+    const dim3 cgrid((units + 3) / 4), cblock(256);
+#define KX_COMBINE(S_)                                                                             \
+  do {                                                                                              \
+    if (rope) hipLaunchKernelGGL((gemm_split_combine_kernel<S_, true>), cgrid, cblock, 0, s, a);     \
+    else hipLaunchKernelGGL((gemm_split_combine_kernel<S_, false>), cgrid, cblock, 0, s, a);         \
+  } while (0)
+    switch (split) {
+      case 4: KX_COMBINE(4); break;
+      case 8: KX_COMBINE(8); break;
+      default: KX_COMBINE(16); break;
+    }
+#undef KX_COMBINE
+    KX_LAUNCH_CHECK();
+  }
   return KX_OK;
 }
 
@@ -922,14 +1070,14 @@ static int gemm_f16act_run(const _Float16* x16, const int8_t* w, const float* sc
   const bool short_rows = T <= 128 && !getenv("KX_GEMM_NO_SHORT");
   if (qkv_form)  // only the pipelined kernel has this epilogue; the caller checked the shape
     return short_rows
-               ? launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_short_kernel>(a, split_ws, split_ws_bytes, s, true)
-               : launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_kernel>(a, split_ws, split_ws_bytes, s, true);
+               ? launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_short_kernel>(a, split_ws, split_ws_bytes, s, true, false, true)
+               : launch_gemm_f16_pipe<gemm_f16_pipe_qkv_rope_kernel>(a, split_ws, split_ws_bytes, s, true, false, true);
   if (choice == 3 && short_rows)
     return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_short_kernel>(a, split_ws, split_ws_bytes, s)
-                  : launch_gemm_f16_pipe<gemm_f16_pipe_short_kernel>(a, split_ws, split_ws_bytes, s);
+                  : launch_gemm_f16_pipe<gemm_f16_pipe_short_kernel>(a, split_ws, split_ws_bytes, s, false, true);
   if (choice == 3)
     return swiglu ? launch_gemm_f16_pipe<gemm_f16_pipe_swiglu_kernel>(a, split_ws, split_ws_bytes, s)
-                  : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, split_ws, split_ws_bytes, s);
+                  : launch_gemm_f16_pipe<gemm_f16_pipe_kernel>(a, split_ws, split_ws_bytes, s, false, true);
   return swiglu ? launch_gemm_f16<2, 2>(gemm_f16_swiglu_kernel_22, a, s)
                 : launch_gemm_f16<2, 2>(gemm_f16_kernel_22, a, s);
 }

@@ -432,8 +432,9 @@ def flash_attention(q, kc, vc, head_num, kv_head_num, head_size, pos, layer_idx,
     return out.numpy(np.float32, q.shape)
 
 
-def gemm_w8_f16act(X16, w, s, group_size=64, swiglu=False, split_ws=None):
-    """fp16 activations [T][M]; fp32 [T][K] out, or fp16 silu(gate)*up [T][K/2] with swiglu.
+def gemm_w8_f16act(X16, w, s, group_size=64, swiglu=False, split_ws=None, residual=None):
+    """fp16 activations [T][M]; fp32 [T][K] out (+ residual [T][K]), or fp16 silu(gate)*up [T][K/2]
+    with swiglu.
     split_ws: a zero-filled Buf of kx_gemm_split_workspace_bytes() lets the kernel cut reductions."""
     K, M = w.shape
     T = X16.shape[0]
@@ -449,8 +450,10 @@ def gemm_w8_f16act(X16, w, s, group_size=64, swiglu=False, split_ws=None):
               "kx_gemm_w8_f16act_split_ws")
         return h.numpy(np.float16, (T, K // 2))
     dy = Buf.zeros((T, K))
+    dr = Buf.from_numpy(np.ascontiguousarray(residual, np.float32)) if residual is not None else None
     check(lib().kx_gemm_w8_f16act_split_ws(dx.ptr, dw.ptr, ds.ptr, group_size, 0, None, dy.ptr, K, None, 0,
-                                           None, 0, K, K, None, 0, T, M, K, ws.ptr, wsb, sp, spb, None),
+                                           None, 0, K, K, dr.ptr if dr else None, K if dr else 0, T, M, K,
+                                           ws.ptr, wsb, sp, spb, None),
           "kx_gemm_w8_f16act_split_ws")
     return dy.numpy(np.float32, (T, K))
 

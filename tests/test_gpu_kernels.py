@@ -990,6 +990,68 @@ def test_gemm_w8_f16_qkv_with_bias_and_rope_in_the_epilogue(hs, variant, T, pos0
                                         None) == -2
 
 
+@pytest.mark.parametrize("hs,variant,T,pos0,parts", [(128, 1, 300, 5, "4"), (64, 1, 530, 0, "8"), (64, 0, 260, 17, "4"),
+                                                     (128, 0, 256, 3, "16"), (128, 1, 40, 2, "8")])
+def test_gemm_w8_f16_cut_reduction_summed_by_a_launch_of_its_own(monkeypatch, hs, variant, T, pos0, parts):
+    # four parts or more: the slabs are summed by a second launch spread over the chip, in part
+    # order like the last arriver's sum, so both give the same bits -- plain, residual and the
+    # Wq|Wk|Wv form (bias, rotary embedding, K / V rows in a wider cache)
+    monkeypatch.setenv("KX_GEMM_F16_KERNEL", "3")
+    monkeypatch.setenv("KX_GEMM_SPLIT", parts)
+    rng = np.random.default_rng(hs + T)
+    L = kx.lib()
+    M, H, KVH = 2048, 4, 2
+    ql, kl = H * hs, KVH * hs
+    K = ql + 2 * kl
+    _, w, s = rand_w8(rng, K, M)
+    X16 = rng.standard_normal((T, M)).astype(np.float16)
+    bias = rng.standard_normal(K).astype(np.float32) * 0.1
+    res = rng.standard_normal((T, K)).astype(np.float32)
+    S = pos0 + T + 3
+    ds_, dc_ = kx.Buf.zeros((S, hs)), kx.Buf.zeros((S, hs))
+    kx.check(L.kx_sin_cos_cache_f32(hs, S, 10000.0, ds_.ptr, dc_.ptr, None))
+    dx, dw, dsc, db = kx.Buf.from_numpy(X16), kx.Buf.from_numpy(w), kx.Buf.from_numpy(s), kx.Buf.from_numpy(bias)
+    wsb = L.kx_gemm_w8_f16act_workspace_bytes(M, K)
+    ws = kx.Buf(wsb)
+    sp = kx.Buf.zeros(L.kx_gemm_split_workspace_bytes(), np.uint8)
+    kst = kl + 64
+
+    def run():
+        plain = kx.gemm_w8_f16act(X16, w, s, GS, split_ws=sp)
+        resid = kx.gemm_w8_f16act(X16, w, s, GS, split_ws=sp, residual=res)
+        q = kx.Buf.zeros((T, ql))
+        kc = kx.Buf.from_numpy(np.full((S, kst), 7.0, np.float32))
+        vc = kx.Buf.from_numpy(np.full((S, kst), 9.0, np.float32))
+        kx.check(L.kx_gemm_w8_f16act_qkv_rope(dx.ptr, dw.ptr, dsc.ptr, GS, 0, q.ptr, ql, kc.at(pos0 * kst * 4), kst,
+                                              vc.at(pos0 * kst * 4), kst, ql, kl, hs, variant, ds_.ptr, dc_.ptr,
+                                              pos0, db.ptr, T, M, ws.ptr, wsb, sp.ptr, sp.nbytes, None))
+        kx.sync()
+        assert not sp.numpy(np.uint8, (4096,)).any()        # tickets back at zero
+        return plain, resid, q.numpy(), kc.numpy(), vc.numpy()
+
+    later = run()
+    monkeypatch.setenv("KX_GEMM_COMBINE", "0")
+    arriver = run()
+    for a, b in zip(later, arriver):
+        assert np.array_equal(a, b)
+    monkeypatch.setenv("KX_GEMM_SPLIT", "1")
+    whole = run()
+    assert not np.array_equal(whole[0], later[0])            # the cut really happened
+    scale = np.abs(whole[0]).max()
+    for a, b in zip(later, whole):
+        assert np.all(np.abs(a - b) <= 2e-5 * scale)
+    plain, _, gq, gk, gv = later
+    pb = plain + bias
+    for r in np.unique(np.r_[0, T - 1, rng.integers(0, T, 6)]):
+        wq, wk = kxo.rope(variant, ql, kl, hs, pb[r, :ql].copy(), pb[r, ql:ql + kl].copy(), pos0 + r,
+                          ds_.numpy(), dc_.numpy())
+        np.testing.assert_allclose(gq[r], wq, rtol=1e-5, atol=2e-5 * scale)
+        np.testing.assert_allclose(gk[pos0 + r, :kl], wk, rtol=1e-5, atol=2e-5 * scale)
+        np.testing.assert_allclose(gv[pos0 + r, :kl], pb[r, ql + kl:], rtol=1e-6, atol=2e-5 * scale)
+    assert np.all(gk[:pos0] == 7.0) and np.all(gk[pos0 + T:] == 7.0) and np.all(gk[:, kl:] == 7.0)
+    assert np.all(gv[:pos0] == 9.0) and np.all(gv[pos0 + T:] == 9.0) and np.all(gv[:, kl:] == 9.0)
+
+
 def test_fp16_activations_saturate_instead_of_overflowing():
     # silu(g) * u and the normalised rows leave as fp16: a value past 65504 must stay finite
     T, K, M = 256, 128, 64
