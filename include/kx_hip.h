@@ -359,6 +359,35 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
                            int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                            int32_t layer_index, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* kx_mha_decode_dpos_f32 that also warms the caches for the launch behind it.  No counterpart in
+ * the reference (its launches start cold: mha_layer->forward, then wo_layer->forward,
+ * llama3.cpp:733-743).  While the last workgroup per kv head merges the splits, HBM is idle and every other
+ * workgroup is done: on their way out those read one dword of every 128-byte line of up to two
+ * byte ranges -- `next0` / `next1`, cut into granules; granule c is what workgroup c of the NEXT
+ * launch reads first (for kx_gemv_w8_f32_ex: kx_gemv_w8_block_rows() rows of the int8 matrix, and
+ * of its scales), and it is read by a workgroup on XCD c mod 8, where workgroup c will run.  Only
+ * the first part of every granule is read, 7 MiB of `next0` in all and the same share of `next1`:
+ * what arrives while the merge runs (more would make this launch end later than the next gains).  The
+ * result is that of kx_mha_decode_dpos_f32 bit for bit; ranges that are null, empty, or not whole
+ * 128-byte lines from a 128-byte aligned start are ignored, and so is everything when the
+ * context is short enough for one split per kv head. */
+int kx_mha_decode_dpos_touch_f32(const float* query, const float* key_cache, const float* value_cache,
+                                 float* out, const int32_t* pos_dev, int32_t max_pos,
+                                 int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t kv_dim,
+                                 int32_t seq_len, int32_t layer_index, void* workspace,
+                                 size_t workspace_bytes, const void* next0, size_t next0_bytes,
+                                 size_t next0_granule, const void* next1, size_t next1_bytes,
+                                 size_t next1_granule, void* stream);
+/* The same for a 16-bit cache (kx_mha_decode_kv16 with the two ranges). */
+int kx_mha_decode_kv16_touch(const float* query, const void* key_cache16, const void* value_cache16,
+                             float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
+                             int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
+                             int32_t layer_index, void* workspace, size_t workspace_bytes,
+                             const void* next0, size_t next0_bytes, size_t next0_granule,
+                             const void* next1, size_t next1_bytes, size_t next1_granule, void* stream);
+/* Rows of a K x M int8 matrix that one workgroup of kx_gemv_w8_f32 / _ex (plain form) owns:
+ * workgroup b reads rows [b * n, (b + 1) * n).  0 when the shape takes the generic kernel. */
+int32_t kx_gemv_w8_block_rows(int32_t M, int32_t K, int32_t group_size);
 /* 16-bit KV cache (not in the reference, whose cache is fp32: kv_cache_manager.cpp:6-40): the same
  * single-token attention over caches of IEEE half rows, same [layer][seq_len][kv_dim] layout.
  * K and V are widened to fp32 on load, so the only deviation from the fp32 cache is the one

@@ -25,7 +25,7 @@
 namespace kx {
 
 // operands of the bounds-checking build
-enum AttnOperand { AB_Q, AB_K, AB_V, AB_OUT, AB_WS, AB_TICKETS, AB_POS };
+enum AttnOperand { AB_Q, AB_K, AB_V, AB_OUT, AB_WS, AB_TICKETS, AB_POS, AB_NEXT0, AB_NEXT1 };
 
 constexpr int kAttnWaves = 4;      // waves per workgroup (the eight-wave form below: NW = 8)
 constexpr int kMaxSplits = 128;
@@ -91,6 +91,76 @@ __device__ __forceinline__ float2 ld_device2(__amdgpu_buffer_rsrc_t r, unsigned 
   return float2{__uint_as_float(v.x), __uint_as_float(v.y)};
 }
 
+// What the launch behind this one reads first (e.g. Wo's int8 rows and their scales), as up to two
+// byte ranges cut into granules of whole 128-byte lines: granule c is what workgroup c of that
+// launch reads, and workgroup c runs on XCD c mod 8.  The split merge at the end of the attention
+// launch leaves HBM idle for a couple of microseconds with all but one workgroup per kv head
+// finished: those workgroups, on their way out, read one dword of every line of the granules that
+// belong to THEIR XCD, so the next launch finds them in that XCD's L2.  Nothing is kept; a launch
+// that touches nothing (no ranges, or a single split) behaves as before.
+struct AttnNext {
+  const char* p[2];
+  unsigned lines[2];       // 128-byte lines in the range
+  unsigned gran_lines[2];  // lines per granule
+  unsigned take_lines[2];  // lines of a granule that are read (its first ones)
+};
+constexpr int kTouchRounds = 4;  // loads per thread and range at most
+// Bytes of the first range read per launch: what HBM delivers while the merge runs.  More makes the
+// launch end later than the next one gains (Llama-3-8B, 4.4 k keys, Wo of 16.8 MB: all of it 480.7
+// tok/s against 480.5 without, 35-50 % of it 485.7-488.1; 10 % 483.8).
+constexpr size_t kTouchBudgetBytes = 7u << 20;
+
+__device__ __forceinline__ void attn_touch_next(const AttnNext& nx, int member, int members KX_BPARAM(9)) {
+  // member: this workgroup's number among the launch's live workgroups, dispatched round-robin
+  // over the XCDs
+  const int xcd = member & 7, j = member >> 3, per_xcd = (members + 7) >> 3;
+  // All loads go out, lanes without a line masked off, and are waited for once -- inside ONE
+  // assembly statement, so that from hipcc's side nothing is in flight when it ends: hipcc does not
+  // track loads issued by inline assembly and would hand their destination registers to other
+  // values while a load may still write them.  (Written as C++ loads, each lane-tested load is
+  // branched around and waited for on its own; made unconditional on a clamped address, thousands
+  // of idle lanes hammer one line.)
+  const char* at[2 * kTouchRounds];
+  unsigned on[2 * kTouchRounds];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned gl = nx.gran_lines[r], tl = nx.p[r] ? nx.take_lines[r] : 1u;
+    const unsigned granules = nx.p[r] ? (nx.lines[r] + gl - 1) / gl : 0u;
+#pragma unroll
+    for (int round = 0; round < kTouchRounds; ++round) {
+      const unsigned idx = threadIdx.x + round * blockDim.x;
+      const unsigned c = xcd + 8u * (j + per_xcd * (idx / tl));
+      const unsigned line = c * gl + idx % tl;
+      const bool ok = c < granules && line < nx.lines[r];
+      const int i = r * kTouchRounds + round;
+      at[i] = nx.p[r] + (size_t)(ok ? line : 0u) * 128;
+      on[i] = ok;
+      if (ok) KX_TOUCHP(r == 0 ? AB_NEXT0 : AB_NEXT1, at[i], 4);
+    }
+  }
+  static_assert(kTouchRounds == 4, "the statement below names eight loads");
+  unsigned o0, o1, o2, o3, o4, o5, o6, o7;
+  unsigned long long live;
+#define KX_TOUCH_ONE(n)                        \
+  "s_mov_b64 exec, %[live]\n\t"               \
+  "v_cmp_ne_u32_e32 vcc, 0, %[p" #n "]\n\t"    \
+  "s_and_b64 exec, %[live], vcc\n\t"          \
+  "global_load_dword %[o" #n "], %[a" #n "], off\n\t"
+  asm volatile("s_mov_b64 %[live], exec\n\t"
+               KX_TOUCH_ONE(0) KX_TOUCH_ONE(1) KX_TOUCH_ONE(2) KX_TOUCH_ONE(3)
+               KX_TOUCH_ONE(4) KX_TOUCH_ONE(5) KX_TOUCH_ONE(6) KX_TOUCH_ONE(7)
+               "s_mov_b64 exec, %[live]\n\t"
+               "s_waitcnt vmcnt(0)"
+               : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4),
+                 [o5] "=&v"(o5), [o6] "=&v"(o6), [o7] "=&v"(o7), [live] "=&s"(live)
+               : [a0] "v"(at[0]), [a1] "v"(at[1]), [a2] "v"(at[2]), [a3] "v"(at[3]), [a4] "v"(at[4]),
+                 [a5] "v"(at[5]), [a6] "v"(at[6]), [a7] "v"(at[7]), [p0] "v"(on[0]), [p1] "v"(on[1]),
+                 [p2] "v"(on[2]), [p3] "v"(on[3]), [p4] "v"(on[4]), [p5] "v"(on[5]), [p6] "v"(on[6]),
+                 [p7] "v"(on[7])
+               : "vcc", "memory");
+#undef KX_TOUCH_ONE
+}
+
 template <int HS>
 struct AttnTile {
   static constexpr int NJ = HS / 16;
@@ -109,7 +179,7 @@ __device__ __forceinline__ f32x4 load_kv4(const _Float16* p) {
 template <int HS, typename KVT>
 __device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __restrict__ kbase,
                                                const KVT* __restrict__ vbase, int key0, int last,
-                                               int kv_dim, int n, int g KX_BPARAM(7)) {
+                                               int kv_dim, int n, int g KX_BPARAM(9)) {
   constexpr int NJ = AttnTile<HS>::NJ, NH = AttnTile<HS>::NH;
   constexpr int DLV = HS >= 64 ? 16 : HS / 4;  // dim-lanes that carry data
   // K: lane (key n, g) loads K[key][16j+4g .. +4)
@@ -146,7 +216,7 @@ struct AttnTile4 {
 template <typename KVT>
 __device__ __forceinline__ void attn_load_tile4(AttnTile4& T, const KVT* __restrict__ kbase,
                                                 const KVT* __restrict__ vbase, int key0, int last,
-                                                int kv_dim, int lane KX_BPARAM(7)) {
+                                                int kv_dim, int lane KX_BPARAM(9)) {
   const KVT* kr = kbase + (size_t)min(key0 + (lane & 15), last) * kv_dim + 4 * (lane >> 4);
 #pragma unroll
   for (int j = 0; j < 8; ++j) T.k[j] = load_kv4(KX_CKPN(AB_K, kr + 16 * j, 4 * sizeof(KVT)));
@@ -172,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
     const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale,
-    unsigned long long* __restrict__ trace KX_BPARAM(7)) {
+    unsigned long long* __restrict__ trace, const AttnNext next KX_BPARAM(9)) {
   // optional timeline (tools/bench_attn.py with KX_ATTN_TRACE): wall-clock stamps (100 MHz), 8 per
   // workgroup
   auto stamp = [&](int slot) {
@@ -494,7 +564,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
   }
   __syncthreads();
   stamp(4);  // ticket drawn
-  if (!sm_last) return;
+  if (!sm_last) {
+    attn_touch_next(next, split * (int)gridDim.x + kvh, nsplit * (int)gridDim.x KX_BFWD);
+    return;
+  }
   // Every byte another workgroup wrote is read below with a device-scope (sc1) load, which goes
   // past this CU's vector cache to where the write-through stores landed; nothing else of theirs
   // is read.  That takes the place of a device-scope acquire fence, whose cache invalidate costs
@@ -580,7 +653,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
 __global__ void attn_decode_generic_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                            const float* __restrict__ vc, float* __restrict__ out,
                                            float* __restrict__ score, int last, int kv_mul,
-                                           int kv_dim, int hs, int seq_len, float scale KX_BPARAM(7)) {
+                                           int kv_dim, int hs, int seq_len, float scale KX_BPARAM(9)) {
   __shared__ float red[16];
   const int h = blockIdx.x;
   const float* qh = q + (size_t)h * hs;
@@ -632,9 +705,10 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
                              float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
                              int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                              int32_t layer_index, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             void* stream, const kx::AttnNext* next_or_null = nullptr) {
   using namespace kx;
   if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
+  const AttnNext next = next_or_null ? *next_or_null : AttnNext{};
   if (pos < 0 || pos >= seq_len || head_num <= 0 || kv_mul <= 0 || head_num % kv_mul) return KX_EINVAL;
   const int kvh = head_num / kv_mul;
   if (kv_dim != kvh * head_size) return KX_EINVAL;
@@ -658,7 +732,7 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
                        reinterpret_cast<const float*>(vc), out,
                        reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes), pos,
                        kv_mul, kv_dim, head_size, seq_len, scale
-                       KX_BPASS(7, query, kc, vc, out, workspace, nullptr, nullptr));
+                       KX_BPASS(9, query, kc, vc, out, workspace, nullptr, nullptr, nullptr, nullptr));
     KX_LAUNCH_CHECK();
     return KX_OK;
   }
@@ -722,12 +796,12 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   do {                                                                                           \
     if (prefetch)                                                                                \
       hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_, NW_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace             \
-                         KX_BPASS(7, query, kc, vc, out, ws, tickets, pos_dev));                        \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace, next       \
+                         KX_BPASS(9, query, kc, vc, out, ws, tickets, pos_dev, next.p[0], next.p[1]));                        \
     else                                                                                         \
       hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_, NW_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace             \
-                         KX_BPASS(7, query, kc, vc, out, ws, tickets, pos_dev));                        \
+                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace, next       \
+                         KX_BPASS(9, query, kc, vc, out, ws, tickets, pos_dev, next.p[0], next.p[1]));                        \
   } while (0)
 #define KX_ATTN_LAUNCH(HS_, M4_) KX_ATTN_LAUNCH_NW(HS_, M4_, 4)
   switch (head_size) {
@@ -777,7 +851,7 @@ extern "C" int kx_mha_decode_scores_f32(const float* query, const float* key_cac
     hipLaunchKernelGGL(attn_decode_generic_kernel, dim3(head_num), dim3(256), 0, (hipStream_t)stream,
                        query, key_cache + layer_off, value_cache + layer_off, out, score, pos, kv_mul,
                        kv_dim, head_size, seq_len, 1.0f / sqrtf((float)head_size)
-                       KX_BPASS(7, query, key_cache, value_cache, out, score, nullptr, nullptr));
+                       KX_BPASS(9, query, key_cache, value_cache, out, score, nullptr, nullptr, nullptr, nullptr));
     KX_LAUNCH_CHECK();
     return KX_OK;
   }
@@ -871,6 +945,49 @@ extern "C" int kx_mha_decode_dpos_f32(const float* query, const float* key_cache
                            stream);
 }
 
+namespace kx {
+// ranges that are not whole 128-byte lines from an aligned start are left out (nothing depends on them)
+static AttnNext attn_next_of(const void* p0, size_t bytes0, size_t gran0, const void* p1, size_t bytes1,
+                             size_t gran1) {
+  AttnNext nx{};
+  const void* ps[2] = {p0, p1};
+  const size_t bs[2] = {bytes0, bytes1}, gs[2] = {gran0, gran1};
+  static const bool off = getenv("KX_ATTN_NO_TOUCH") != nullptr;  // A/B runs
+  for (int r = 0; r < 2; ++r) {
+    if (off || !ps[r] || !bs[r] || !gs[r] || gs[r] % 128 || bs[r] % 128 || (uintptr_t)ps[r] % 128) continue;
+    if (bs[r] / 128 > 0x7fffffffu / 2) continue;
+    nx.p[r] = static_cast<const char*>(ps[r]);
+    nx.lines[r] = (unsigned)(bs[r] / 128);
+    nx.gran_lines[r] = (unsigned)(gs[r] / 128);
+  }
+  // the same share of every granule, of both ranges: the first range's budget over its size
+  // (KX_ATTN_TOUCH_PCT: that share in percent, for A/B runs)
+  static const int pct = getenv("KX_ATTN_TOUCH_PCT") ? atoi(getenv("KX_ATTN_TOUCH_PCT")) : 0;
+  const size_t ref_bytes = nx.p[0] ? (size_t)nx.lines[0] * 128 : nx.p[1] ? (size_t)nx.lines[1] * 128 : 1;
+  const double share = pct > 0 ? std::min(100, pct) / 100.0 : std::min(1.0, (double)kTouchBudgetBytes / (double)ref_bytes);
+  for (int r = 0; r < 2; ++r) {
+    if (!nx.p[r]) continue;
+    nx.take_lines[r] = std::max(1u, (unsigned)(nx.gran_lines[r] * share + 0.5));
+  }
+  return nx;
+}
+}  // namespace kx
+
+extern "C" int kx_mha_decode_dpos_touch_f32(const float* query, const float* key_cache,
+                                            const float* value_cache, float* out,
+                                            const int32_t* pos_dev, int32_t max_pos, int32_t head_num,
+                                            int32_t kv_mul, int32_t head_size, int32_t kv_dim,
+                                            int32_t seq_len, int32_t layer_index, void* workspace,
+                                            size_t workspace_bytes, const void* next0,
+                                            size_t next0_bytes, size_t next0_granule, const void* next1,
+                                            size_t next1_bytes, size_t next1_granule, void* stream) {
+  if (!pos_dev) return KX_EINVAL;
+  const kx::AttnNext nx = kx::attn_next_of(next0, next0_bytes, next0_granule, next1, next1_bytes, next1_granule);
+  return mha_decode_launch<float>(query, key_cache, value_cache, out, max_pos, pos_dev, head_num, kv_mul,
+                                  head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
+                                  stream, &nx);
+}
+
 extern "C" int kx_mha_decode_kv16(const float* query, const void* key_cache16,
                                   const void* value_cache16, float* out, int32_t pos,
                                   const int32_t* pos_dev, int32_t head_num, int32_t kv_mul,
@@ -881,4 +998,19 @@ extern "C" int kx_mha_decode_kv16(const float* query, const void* key_cache16,
                                      static_cast<const _Float16*>(value_cache16), out, pos, pos_dev,
                                      head_num, kv_mul, head_size, kv_dim, seq_len, layer_index,
                                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int kx_mha_decode_kv16_touch(const float* query, const void* key_cache16,
+                                        const void* value_cache16, float* out, int32_t pos,
+                                        const int32_t* pos_dev, int32_t head_num, int32_t kv_mul,
+                                        int32_t head_size, int32_t kv_dim, int32_t seq_len,
+                                        int32_t layer_index, void* workspace, size_t workspace_bytes,
+                                        const void* next0, size_t next0_bytes, size_t next0_granule,
+                                        const void* next1, size_t next1_bytes, size_t next1_granule,
+                                        void* stream) {
+  const kx::AttnNext nx = kx::attn_next_of(next0, next0_bytes, next0_granule, next1, next1_bytes, next1_granule);
+  return mha_decode_launch<_Float16>(query, static_cast<const _Float16*>(key_cache16),
+                                     static_cast<const _Float16*>(value_cache16), out, pos, pos_dev,
+                                     head_num, kv_mul, head_size, kv_dim, seq_len, layer_index,
+                                     workspace, workspace_bytes, stream, &nx);
 }

@@ -462,6 +462,55 @@ static int launch(const GemvW8Args& a, int threads, hipStream_t s) {
   return KX_OK;
 }
 
+// Workgroup shape of the fast path for a matrix of out_rows x M (out_rows: gate/up PAIRS in the
+// gate/up form): threads per workgroup, rows a wave keeps in flight together (R), and the rows a
+// workgroup owns -- workgroup b reads rows [b * rows_per_block, (b + 1) * rows_per_block).
+struct GemvGeometry {
+  int threads, R, rows_per_block;
+  bool tall_x;
+};
+static GemvGeometry gemv_geometry(int mode, int M, int out_rows) {
+  const int chunks = (M + 1023) / 1024;
+  const size_t lds = (size_t)chunks * 4096;
+  // waves per CU are bounded by how many x copies fit in the 160 KiB LDS
+  int threads = 256;
+  if (lds > 32 * 1024) threads = 512;
+  if (lds > 80 * 1024) threads = 1024;
+  // Few rows of many chunks (W2: 4096 x 14336, one block per CU): 16 waves of one row each
+  // instead of 8 waves of two -- x is staged in one pass per thread and twice the waves hide each
+  // other's round trips (13.0 -> 12.2 us) -- as long as all blocks are resident at once.
+  bool tall_x = false;
+  if (mode == GEMV_PLAIN && chunks > 8) {
+    const int rpb1 = std::max((out_rows + 1023) / 1024, 16);
+    const int blocks1 = (out_rows + rpb1 - 1) / rpb1;
+    const int fit = std::max<int>(1, (int)((160 * 1024 - 64) / lds));
+    tall_x = blocks1 <= 256 * fit;
+    if (tall_x) threads = 1024;
+  }
+  // Few rows in all (fewer than 8 waves per CU at the usual rows per wave; Llama-3.2-1B: Wo 2048 x 2048,
+  // W2 2048 x 8192): one row per wave as well, in smaller workgroups -- twice to four times the
+  // waves hide each other's latency (3.9 -> 3.2 us and 6.8 -> 5.5 us on those two).
+  if (mode == GEMV_PLAIN && !tall_x && out_rows / (chunks <= 2 ? 4 : 2) < 2048) {
+    tall_x = true;
+    threads = chunks >= 2 ? 512 : 256;
+  }
+  // rows a wave keeps in flight together; the gate/up form already doubles the loads.  The fused
+  // QKV form needs both rows of a rotation pair in one wave and is best at exactly two (3072 x 2048:
+  // 5.6 us with four rows per wave, 4.3 us with two).
+  const int R = tall_x ? 1 : mode == GEMV_GATE_UP ? 1 : mode == GEMV_QKV_ROPE ? 2 : (chunks <= 2 ? 4 : 2);
+  const int per_iter = (threads / 64) * R;
+  // aim for ~4 workgroups per CU on big matrices, one pass on small ones
+  const int target_blocks = 256 * 4;
+  int rpb = (out_rows + target_blocks - 1) / target_blocks;
+  // Every wave gets work (at least one row set per wave); beyond that only whole row sets, so the
+  // grid stays a multiple of the CU count where the row count allows it: 14336 gate/up pairs are
+  // 1024 blocks of 14 (waves take 4, 4, 3, 3), not 896 blocks of 16 that leave half of the CUs
+  // with a fourth block to finish.
+  if (rpb < per_iter) rpb = per_iter;
+  rpb = ((rpb + R - 1) / R) * R;
+  return GemvGeometry{threads, R, rpb, tall_x};
+}
+
 static int ilog2(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
@@ -493,45 +542,11 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
   a.chunks = (a.M + 1023) / 1024;
   a.gs_shift = ilog2(group_size);
   a.groups_per_row = a.M / group_size;
-  const size_t lds = (size_t)a.chunks * 4096;
-  // waves per CU are bounded by how many x copies fit in the 160 KiB LDS
-  int threads = 256;
-  if (lds > 32 * 1024) threads = 512;
-  if (lds > 80 * 1024) threads = 1024;
   const int out_rows = mode == GEMV_GATE_UP ? a.swiglu_half : a.K;
-  // Few rows of many chunks (W2: 4096 x 14336, one block per CU): 16 waves of one row each
-  // instead of 8 waves of two -- x is staged in one pass per thread and twice the waves hide each
-  // other's round trips (13.0 -> 12.2 us) -- as long as all blocks are resident at once.
-  bool tall_x = false;
-  if (mode == GEMV_PLAIN && a.chunks > 8) {
-    const int rpb1 = std::max((out_rows + 1023) / 1024, 16);
-    const int blocks1 = (out_rows + rpb1 - 1) / rpb1;
-    const int fit = std::max<int>(1, (int)((160 * 1024 - 64) / lds));
-    tall_x = blocks1 <= 256 * fit;
-    if (tall_x) threads = 1024;
-  }
-  // Few rows in all (fewer than 8 waves per CU at the usual rows per wave; Llama-3.2-1B: Wo 2048 x 2048,
-  // W2 2048 x 8192): one row per wave as well, in smaller workgroups -- twice to four times the
-  // waves hide each other's latency (3.9 -> 3.2 us and 6.8 -> 5.5 us on those two).
-  if (mode == GEMV_PLAIN && !tall_x && out_rows / (a.chunks <= 2 ? 4 : 2) < 2048) {
-    tall_x = true;
-    threads = a.chunks >= 2 ? 512 : 256;
-  }
-  // rows a wave keeps in flight together; the gate/up form already doubles the loads.  The fused
-  // QKV form needs both rows of a rotation pair in one wave and is best at exactly two (3072 x 2048:
-  // 5.6 us with four rows per wave, 4.3 us with two).
-  const int R = tall_x ? 1 : mode == GEMV_GATE_UP ? 1 : mode == GEMV_QKV_ROPE ? 2 : (a.chunks <= 2 ? 4 : 2);
-  const int per_iter = (threads / 64) * R;
-  // aim for ~4 workgroups per CU on big matrices, one pass on small ones
-  const int target_blocks = 256 * 4;
-  int rpb = (out_rows + target_blocks - 1) / target_blocks;
-  // Every wave gets work (at least one row set per wave); beyond that only whole row sets, so the
-  // grid stays a multiple of the CU count where the row count allows it: 14336 gate/up pairs are
-  // 1024 blocks of 14 (waves take 4, 4, 3, 3), not 896 blocks of 16 that leave half of the CUs
-  // with a fourth block to finish.
-  if (rpb < per_iter) rpb = per_iter;
-  rpb = ((rpb + R - 1) / R) * R;
-  a.rows_per_block = rpb;
+  const GemvGeometry geo = gemv_geometry(mode, a.M, out_rows);
+  const int threads = geo.threads;
+  const bool tall_x = geo.tall_x;
+  a.rows_per_block = geo.rows_per_block;
   // (R, U) per mode from a sweep on MI355X: more loads per wave than these lowers occupancy and
   // loses; two register sets per wave (software pipelining) lost 30 % against plain occupancy
   switch (mode) {
@@ -549,6 +564,13 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
 }
 
 }  // namespace kx
+
+extern "C" int32_t kx_gemv_w8_block_rows(int32_t M, int32_t K, int32_t group_size) {
+  if (M <= 0 || K <= 0 || group_size <= 0 || M % 16 || M % group_size || group_size % 16 ||
+      (group_size & (group_size - 1)) || (size_t)((M + 1023) / 1024) * 4096 > 160 * 1024 - 64)
+    return 0;
+  return kx::gemv_geometry(kx::GEMV_PLAIN, M, K).rows_per_block;
+}
 
 extern "C" int kx_gemv_w8_f32_ex(const float* x, const int8_t* w, const float* scales,
                                  int32_t group_size, float* y0, float* y1, float* y2, int32_t k0,

@@ -861,16 +861,28 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
     auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
     ST_RET(gemv(lw.qkv, KX_GEMV_QKV_ROPE, x_, lw.attn_norm, q_, static_cast<float*>(k_ptr),
                 static_cast<float*>(v_ptr), ql, ql + kl, nullptr, st));
-    if (all && c.kv_f16)
-      KX_RET(kx_mha_decode_kv16(q_, kv_->get_raw_buffer_k(), kv_->get_raw_buffer_v(), att_,
-                                c.seq_len - 1, pos_dev_, c.head_local, c.kv_mul, c.head_size, kl,
-                                c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes, st));
-    else if (all)
-      KX_RET(kx_mha_decode_dpos_f32(q_, static_cast<float*>(kv_->get_raw_buffer_k()),
-                                    static_cast<float*>(kv_->get_raw_buffer_v()), att_, pos_dev_,
-                                    c.seq_len - 1, c.head_local, c.kv_mul, c.head_size, kl,
-                                    c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes,
-                                    st));
+    if (all) {
+      // while the attention launch's last workgroups merge the splits, the finished ones read the
+      // head of Wo's row blocks and scales into the XCD caches where the Wo GEMV's workgroups
+      // will want them
+      const int32_t rpb = kx_gemv_w8_block_rows(lw.wo.cols, lw.wo.rows, c.group_size);
+      const size_t wo_bytes = (size_t)lw.wo.rows * lw.wo.cols;
+      const void* n0 = rpb > 0 ? lw.wo.w : nullptr;
+      const void* n1 = rpb > 0 ? lw.wo.s : nullptr;
+      const size_t g0 = (size_t)rpb * lw.wo.cols, b1 = wo_bytes / c.group_size * sizeof(float),
+                   g1 = g0 / c.group_size * sizeof(float);
+      if (c.kv_f16)
+        KX_RET(kx_mha_decode_kv16_touch(q_, kv_->get_raw_buffer_k(), kv_->get_raw_buffer_v(), att_,
+                                        c.seq_len - 1, pos_dev_, c.head_local, c.kv_mul, c.head_size, kl,
+                                        c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes,
+                                        n0, wo_bytes, g0, n1, b1, g1, st));
+      else
+        KX_RET(kx_mha_decode_dpos_touch_f32(q_, static_cast<float*>(kv_->get_raw_buffer_k()),
+                                            static_cast<float*>(kv_->get_raw_buffer_v()), att_, pos_dev_,
+                                            c.seq_len - 1, c.head_local, c.kv_mul, c.head_size, kl,
+                                            c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes,
+                                            n0, wo_bytes, g0, n1, b1, g1, st));
+    }
     // row-parallel: every rank holds a partial sum; rank 0 carries the residual into the sum
     const float* res = c.plan.carries_residual ? x_ : nullptr;
     ST_RET(gemv(lw.wo, KX_GEMV_PLAIN, att_, nullptr, x_, nullptr, nullptr, 0, 0, res, st));

@@ -354,6 +354,87 @@ def test_mha_decode_device_position_one_workspace_many_launches():
     assert L.kx_attn_workspace_reset(ws.ptr, 100, None) == -1
 
 
+@pytest.mark.parametrize("H,KVH,hs,S,K,M", [(32, 8, 128, 4736, 4096, 4096), (32, 8, 128, 2304, 4000, 4096),
+                                            (6, 2, 64, 1200, 1536, 384), (16, 2, 128, 4500, 2048, 2048)])
+def test_mha_decode_that_warms_the_next_launch_gives_the_same_bits(H, KVH, hs, S, K, M, monkeypatch):
+    # the touching entries read the head of the granules of a following K x M GEMV (int8 rows and
+    # scales, buffers of exactly that size: the bounds-checking build sees every touched address)
+    # and change nothing: same bits as the plain entry, workspace tickets at zero, the touched
+    # buffers untouched; a ragged last granule, a range that is not whole lines, a null range,
+    # a share of 100 %, a single split and the 16-bit cache form included
+    rng = np.random.default_rng(S + K)
+    kvd = KVH * hs
+    kc = rng.standard_normal((1, S, kvd)).astype(np.float32)
+    vc = rng.standard_normal((1, S, kvd)).astype(np.float32)
+    q = rng.standard_normal(H * hs).astype(np.float32)
+    L = kx.lib()
+    rpb = L.kx_gemv_w8_block_rows(M, K, GS)
+    assert rpb > 0
+    w = rng.integers(-127, 128, size=(K, M), dtype=np.int8)
+    sc = rng.uniform(1e-4, 3e-4, size=K * M // GS).astype(np.float32)
+    dw, dsc = kx.Buf.from_numpy(w), kx.Buf.from_numpy(sc)
+    dq, dk, dv = kx.Buf.from_numpy(q), kx.Buf.from_numpy(kc), kx.Buf.from_numpy(vc)
+    dk16, dv16 = kx.Buf.from_numpy(kc.astype(np.float16)), kx.Buf.from_numpy(vc.astype(np.float16))
+    wsb = L.kx_attn_workspace_bytes(H, hs)
+    ws = kx.Buf.zeros(wsb, np.uint8)
+    pos_dev = kx.Buf.zeros(1, np.int32)
+    g0, g1 = rpb * M, rpb * M // GS * 4
+
+    def plain(pos, half):
+        out = kx.Buf.zeros(H * hs)
+        if half:
+            kx.check(L.kx_mha_decode_kv16(dq.ptr, dk16.ptr, dv16.ptr, out.ptr, S - 1, pos_dev.ptr, H, H // KVH, hs,
+                                          kvd, S, 0, ws.ptr, wsb, None))
+        else:
+            kx.check(L.kx_mha_decode_dpos_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H, H // KVH, hs,
+                                              kvd, S, 0, ws.ptr, wsb, None))
+        kx.sync()
+        return out.numpy()
+
+    def touching(pos, half, n0, b0, gr0, n1, b1, gr1):
+        out = kx.Buf.zeros(H * hs)
+        if half:
+            kx.check(L.kx_mha_decode_kv16_touch(dq.ptr, dk16.ptr, dv16.ptr, out.ptr, S - 1, pos_dev.ptr, H, H // KVH,
+                                                hs, kvd, S, 0, ws.ptr, wsb, n0, b0, gr0, n1, b1, gr1, None))
+        else:
+            kx.check(L.kx_mha_decode_dpos_touch_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H, H // KVH,
+                                                    hs, kvd, S, 0, ws.ptr, wsb, n0, b0, gr0, n1, b1, gr1, None))
+        kx.sync()
+        return out.numpy()
+
+    for pos in (S - 1, S // 2, 40, 3):
+        pos_dev.upload(np.array([pos], np.int32))
+        for half in (False, True):
+            base = plain(pos, half)
+            if not half:
+                want = kxo.mha(pos, H, 0, S, kvd, H // KVH, hs, q, kc, vc).reshape(-1)
+                np.testing.assert_allclose(base, want, rtol=0, atol=2e-5)
+            for pct in ("", "100", "3"):
+                if pct:
+                    monkeypatch.setenv("KX_ATTN_TOUCH_PCT", pct)
+                else:
+                    monkeypatch.delenv("KX_ATTN_TOUCH_PCT", raising=False)
+                assert np.array_equal(touching(pos, half, dw.ptr, K * M, g0, dsc.ptr, sc.nbytes, g1), base)
+            monkeypatch.delenv("KX_ATTN_TOUCH_PCT", raising=False)
+            # one range only; a range that is not whole lines (ignored); granules that do not divide the range
+            assert np.array_equal(touching(pos, half, None, 0, 0, dsc.ptr, sc.nbytes, g1), base)
+            assert np.array_equal(touching(pos, half, dw.ptr, K * M - 64, g0, None, 0, 0), base)
+            assert np.array_equal(touching(pos, half, dw.ptr, K * M, 3 * 128, dsc.ptr, sc.nbytes, 5 * 128), base)
+    assert not ws.numpy(np.uint8, (wsb,))[:16384].any()
+    assert np.array_equal(dw.numpy(np.int8, (K, M)), w) and np.array_equal(dsc.numpy(), sc)
+
+
+def test_gemv_w8_block_rows_is_what_the_kernel_uses():
+    # rows per workgroup of the plain GEMV; 0 for shapes that take the generic kernel
+    L = kx.lib()
+    assert L.kx_gemv_w8_block_rows(4096, 4096, 64) == 8
+    assert L.kx_gemv_w8_block_rows(14336, 4096, 64) == 16
+    assert L.kx_gemv_w8_block_rows(4096, 128256, 64) == 126
+    assert L.kx_gemv_w8_block_rows(2048, 2048, 64) == 8
+    assert L.kx_gemv_w8_block_rows(100, 64, 4) == 0
+    assert L.kx_gemv_w8_block_rows(0, 64, 64) == 0
+
+
 def test_mha_decode_forced_rescale_and_no_workspace():
     # one key far above the rest late in the sequence forces the online-softmax rescale branch;
     # with no workspace the kernel must fall back to a single split and still be right
