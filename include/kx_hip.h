@@ -366,8 +366,9 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
  * byte ranges -- `next0` / `next1`, cut into granules; granule c is what workgroup c of the NEXT
  * launch reads first (for kx_gemv_w8_f32_ex: kx_gemv_w8_block_rows() rows of the int8 matrix, and
  * of its scales), and it is read by a workgroup on XCD c mod 8, where workgroup c will run.  Only
- * the first part of every granule is read, 7 MiB of `next0` in all and the same share of `next1`:
- * what arrives while the merge runs (more would make this launch end later than the next gains).  The
+ * the first part of every granule is read -- 7 MiB of `next0` in all, 40 % of it at most, and the
+ * same share of `next1`: what arrives while the merge runs (more would make this launch end
+ * later than the next gains).  The
  * result is that of kx_mha_decode_dpos_f32 bit for bit; ranges that are null, empty, or not whole
  * 128-byte lines from a 128-byte aligned start are ignored, and so is everything when the
  * context is short enough for one split per kv head. */

@@ -109,6 +109,9 @@ constexpr int kTouchRounds = 4;  // loads per thread and range at most
 // launch end later than the next one gains (Llama-3-8B, 4.4 k keys, Wo of 16.8 MB: all of it 480.7
 // tok/s against 480.5 without, 35-50 % of it 485.7-488.1; 10 % 483.8).
 constexpr size_t kTouchBudgetBytes = 7u << 20;
+// ... and never more than this share of a range: small matrices (Llama-3.2-1B: Wo of 4.2 MB, a
+// shorter merge) lose 0.35 % with all of it and nothing with 40 %.
+constexpr double kTouchShareMost = 0.4;
 
 __device__ __forceinline__ void attn_touch_next(const AttnNext& nx, int member, int members KX_BPARAM(9)) {
   // member: this workgroup's number among the launch's live workgroups, dispatched round-robin
@@ -964,7 +967,7 @@ static AttnNext attn_next_of(const void* p0, size_t bytes0, size_t gran0, const 
   // (KX_ATTN_TOUCH_PCT: that share in percent, for A/B runs)
   static const int pct = getenv("KX_ATTN_TOUCH_PCT") ? atoi(getenv("KX_ATTN_TOUCH_PCT")) : 0;
   const size_t ref_bytes = nx.p[0] ? (size_t)nx.lines[0] * 128 : nx.p[1] ? (size_t)nx.lines[1] * 128 : 1;
-  const double share = pct > 0 ? std::min(100, pct) / 100.0 : std::min(1.0, (double)kTouchBudgetBytes / (double)ref_bytes);
+  const double share = pct > 0 ? std::min(100, pct) / 100.0 : std::min(kTouchShareMost, (double)kTouchBudgetBytes / (double)ref_bytes);
   for (int r = 0; r < 2; ++r) {
     if (!nx.p[r]) continue;
     nx.take_lines[r] = std::max(1u, (unsigned)(nx.gran_lines[r] * share + 0.5));

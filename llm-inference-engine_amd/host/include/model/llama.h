@@ -179,6 +179,7 @@ class LlamaModel {
                              int32_t g_rows, int32_t g_cols, int32_t row0, int32_t rows,
                              int32_t col0, int32_t cols);
   static constexpr int32_t kPrefillChunk = 4096;  // prompt rows per batched pass
+  static constexpr int32_t kPiecesMaxRows = 304;  // longest prompt cut into few-rows pieces (no fp16 images)
   base::Status reserve_weight_images();
   void drop_weight_images(bool free_memory);
   int weight_images_ = 0;  // 0 not decided yet, 1 in use, -1 not available

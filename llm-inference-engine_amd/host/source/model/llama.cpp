@@ -1035,20 +1035,20 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
   const int32_t ql = c.q_dim_local, kl = c.kv_dim_local, hl = c.hidden_local, dim = c.dim;
   int32_t chunk = n < kPrefillChunk ? n : kPrefillChunk;
   {
-    // A prompt of 193..384 rows on a model WITHOUT fp16 weight images (policy 0, or images that do
+    // A prompt of 193..304 rows on a model WITHOUT fp16 weight images (policy 0, or images that do
     // not fit) runs as two pieces of at most 192 rows through the few-rows kernel, which streams the
-    // int8 weights once per piece (Llama-3-8B: 224 / 256 / 320 / 384 rows in 10.6 / 10.9 / 12.6 /
-    // 13.9 ms against 18.5 / 18.9 / 21.4 / 22.2 ms for the int8 single-pass kernel those lengths got
-    // before).  Three pieces (448 rows: 18.1 ms) lose to converting the weights per pass and running
-    // the fp16 GEMMs (512 rows: 16.9 ms), which therefore starts at 385 rows; with kept images the
-    // fp16 GEMMs win from 193 rows.
+    // int8 weights once per piece (Llama-3-8B: 224 / 256 / 288 rows in 11.0 / 11.4 / 12.6 ms against
+    // 18.5 / 18.9 / 20 ms for the int8 single-pass kernel those lengths got before).  From 305 rows
+    // converting the weights per pass and running the fp16 GEMMs is faster (320 / 352 / 384 rows:
+    // 12.8 / 13.2 / 13.3 ms against 13.2 / 14.0 / 14.6 ms in pieces, one box; equal at 304); with
+    // kept images the fp16 GEMMs win from 193 rows.
     const int gs0 = c.group_size;
     const bool attn16 = c.head_size == 32 || c.head_size == 64 || c.head_size == 128;
     const bool rows_ok = gs0 == 64 && dim % 256 == 0 && ql % 256 == 0 && hl % 256 == 0 && attn16 &&
                          getenv("KX_PREFILL_NO_ROWS_KERNEL") == nullptr && getenv("KX_PREFILL_ROWS_MAX") == nullptr;
     const bool f16_shapes = (gs0 & (gs0 - 1)) == 0 && gs0 >= 16 && dim % 64 == 0 && ql % 64 == 0 && hl % 64 == 0 &&
                             dim % gs0 == 0 && ql % gs0 == 0 && hl % gs0 == 0 && attn16;
-    if (rows_ok && n > 192 && n <= 384 && getenv("KX_PREFILL_NO_PIECES") == nullptr) {
+    if (rows_ok && n > 192 && n <= kPiecesMaxRows && getenv("KX_PREFILL_NO_PIECES") == nullptr) {
       if (f16_shapes) ST_RET(reserve_weight_images());  // the decision a 193+ row prompt makes anyway
       if (weight_images_ != 1) {
         const int32_t pieces = (n + 191) / 192;
@@ -1157,7 +1157,7 @@ base::Status LlamaModel::prefill(const int32_t* tokens, int32_t n, int32_t pos0,
     const bool rows_fused = few_rows && !env_unfused;
     const bool rows_fused_rope = rows_fused && ql % 128 == 0 && kl % 128 == 0;
     if (!few_rows && f16_ok && rows >= 32) ST_RET(reserve_weight_images());
-    int32_t f16_min_rows = weight_images_ == 1 ? 32 : 385;
+    int32_t f16_min_rows = weight_images_ == 1 ? 32 : kPiecesMaxRows + 1;
     if (env_f16_min) f16_min_rows = atoi(env_f16_min);
     const bool f16_chunk = !few_rows && f16_ok && rows >= f16_min_rows;
     for (int32_t l = 0; l < c.layer_num; ++l) {

@@ -556,8 +556,8 @@ def test_prompts_up_to_192_rows_stream_the_int8_weights(monkeypatch):
         x.close()
 
 
-def test_prompts_of_193_to_384_rows_without_weight_images_run_as_pieces(monkeypatch):
-    # no fp16 images (policy 0): a prompt of 193..384 rows is cut into two pieces of at most
+def test_prompts_of_193_to_304_rows_without_weight_images_run_as_pieces(monkeypatch):
+    # no fp16 images (policy 0): a prompt of 193..304 rows is cut into two pieces of at most
     # 192 rows, each through the few-rows kernel on the int8 weights, later pieces attending the
     # earlier ones' cache rows.  Within the batched-prompt tolerance of one fp32 decode step per row,
     # K/V rows included; the single-pass int8 kernel (pieces switched off) stays within it too; with
@@ -569,7 +569,7 @@ def test_prompts_of_193_to_384_rows_without_weight_images_run_as_pieces(monkeypa
     m.init_synthetic(31)
     ref = host.Model(seq_len=640, group_size=GS, **shape)
     ref.init_synthetic(31)
-    for n in (193, 256, 300, 384, 385, 448):  # 385+: weights converted per pass, fp16 GEMMs
+    for n in (193, 256, 300, 304, 305, 384, 448):  # 305+: weights converted per pass, fp16 GEMMs
         p = rng.integers(0, 1000, n).astype(np.int32)
         got = m.prefill(p)
         assert m.weight_image_bytes() == 0

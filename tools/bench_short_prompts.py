@@ -30,12 +30,12 @@ for T in (4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 384, 512, 768):
         line += f"  {tag}: {best*1e3:7.2f} ms {T/best:8.0f} tok/s"
     print(line, flush=True)
 os.environ.pop("KX_PREFILL_NO_ROWS_KERNEL", None)
-# the same lengths on the int8 weights alone (policy 0: no fp16 image kept): 193..448 rows run as
-# pieces of at most 192 rows through the few-rows kernel; KX_PREFILL_NO_PIECES=1 = the int8
-# single-pass kernel (below 512 rows) / per-pass conversion + fp16 GEMMs (from 512) they would get
+# the same lengths on the int8 weights alone (policy 0: no fp16 image kept): 193..304 rows run as
+# pieces of at most 192 rows through the few-rows kernel, longer ones convert the weights per pass
+# and run the fp16 GEMMs; KX_PREFILL_NO_PIECES=1 = the int8 single-pass kernel in place of the pieces
 model.set_prefill_weight_cache(0)
 print("no fp16 weight images (prefill_weight_cache = 0):", flush=True)
-for T in (192, 224, 256, 320, 384, 400, 448, 512, 768):
+for T in (192, 224, 256, 304, 320, 384, 400, 448, 512, 768):
     prompt = rng.integers(0, shape["vocab_size"], T).astype(np.int32)
     line = f"T={T:4d}"
     for tag, off in (("engine", None), ("whole prompt in one pass", "1")):
