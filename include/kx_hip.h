@@ -359,7 +359,17 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
                            int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                            int32_t layer_index, void* workspace, size_t workspace_bytes,
                            void* stream);
-/* kx_mha_decode_dpos_f32 that also warms the caches for the launch behind it.  No counterpart in
+/* kx_mha_decode_dpos_f32 with two hints from a caller that knows more than one launch.  No
+ * counterpart in the reference.
+ * rows_to_max_pos_readable (0 / 1): with 1 the caller vouches that rows 0..max_pos of the layer
+ * may be READ whatever the position turns out to be -- they are allocated and hold finite numbers
+ * (rows above the position get zero weight; a zero-filled or previously used cache qualifies).
+ * The launch is then cut into splits and tiles for max_pos itself and the position read from
+ * pos_dev only masks, so no cache address waits for it: one dependent memory round trip less
+ * between the launch and the stream.  Every row up to max_pos is read: keep max_pos close above
+ * the positions the launch will really see (model::LlamaModel captures its step for 256
+ * positions at a time).  The position must not exceed max_pos, as for kx_mha_decode_dpos_f32.
+ * next0 / next1: warm the caches for the launch behind this one.  No counterpart in
  * the reference (its launches start cold: mha_layer->forward, then wo_layer->forward,
  * llama3.cpp:733-743).  While the last workgroup per kv head merges the splits, HBM is idle and every other
  * workgroup is done: on their way out those read one dword of every 128-byte line of up to two
@@ -372,16 +382,16 @@ int kx_mha_decode_dpos_f32(const float* query, const float* key_cache, const flo
  * result is that of kx_mha_decode_dpos_f32 bit for bit; ranges that are null, empty, or not whole
  * 128-byte lines from a 128-byte aligned start are ignored, and so is everything when the
  * context is short enough for one split per kv head. */
-int kx_mha_decode_dpos_touch_f32(const float* query, const float* key_cache, const float* value_cache,
+int kx_mha_decode_dpos_ex_f32(const float* query, const float* key_cache, const float* value_cache,
                                  float* out, const int32_t* pos_dev, int32_t max_pos,
-                                 int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t kv_dim,
+                                 int32_t rows_to_max_pos_readable, int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t kv_dim,
                                  int32_t seq_len, int32_t layer_index, void* workspace,
                                  size_t workspace_bytes, const void* next0, size_t next0_bytes,
                                  size_t next0_granule, const void* next1, size_t next1_bytes,
                                  size_t next1_granule, void* stream);
-/* The same for a 16-bit cache (kx_mha_decode_kv16 with the two ranges). */
-int kx_mha_decode_kv16_touch(const float* query, const void* key_cache16, const void* value_cache16,
-                             float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
+/* The same for a 16-bit cache (kx_mha_decode_kv16 with the two hints; `pos` is max_pos when pos_dev is given). */
+int kx_mha_decode_kv16_ex(const float* query, const void* key_cache16, const void* value_cache16,
+                             float* out, int32_t pos, const int32_t* pos_dev, int32_t rows_to_pos_readable, int32_t head_num,
                              int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                              int32_t layer_index, void* workspace, size_t workspace_bytes,
                              const void* next0, size_t next0_bytes, size_t next0_granule,

@@ -240,17 +240,24 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // NW: waves per workgroup.  8 (one workgroup per CU; 4x4x1 forms only, whose per-wave results are
 // small enough for LDS) halves the number of splits a long context is cut into at the same number
 // of waves in flight: half the partials to publish, acknowledge and merge behind the stream.
-template <int HS, bool PREFETCH, typename KVT, int M4 = 0, int NW = kAttnWaves>
+// STATIC: the cut into splits and tiles is that of last_val (an upper bound of the position, passed
+// by value) and the position read from the device only masks: rows above it get zero weight.  The
+// position is then first needed at the softmax of a wave's first tile instead of ahead of the first
+// cache row's address -- one dependent memory round trip less between the launch and the stream.
+// The rows up to last_val must be readable and hold finite numbers.
+template <int HS, bool PREFETCH, typename KVT, int M4 = 0, int NW = kAttnWaves, bool STATIC = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
     const float* __restrict__ q, const KVT* __restrict__ kc, const KVT* __restrict__ vc,
     float* __restrict__ out, float* __restrict__ ws, unsigned* __restrict__ tickets, int last_val,
-    const int32_t* __restrict__ pos_dev, int kv_mul, int kv_dim, float scale,
+    const int32_t* __restrict__ pos_dev, int grid_kvh, int grid_splits, int kv_mul, int kv_dim, float scale,
     unsigned long long* __restrict__ trace, const AttnNext next KX_BPARAM(9)) {
   // optional timeline (tools/bench_attn.py with KX_ATTN_TRACE): wall-clock stamps (100 MHz), 8 per
   // workgroup
+  // grid_kvh x grid_splits: the grid, as arguments (they come with the other arguments; hipcc fetched
+  // gridDim with a vector load of its own in some instantiations)
   auto stamp = [&](int slot) {
     if (trace && threadIdx.x == 0)
-      trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = wall_clock64();
+      trace[((size_t)blockIdx.y * grid_kvh + blockIdx.x) * 8 + slot] = wall_clock64();
   };
   stamp(0);
   constexpr int NJ = AttnTile<HS>::NJ;  // float4 K loads per lane per tile
@@ -270,9 +277,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
   const int kvh = blockIdx.x, split = blockIdx.y;
   // The position may live in device memory so a captured launch can be replayed as it advances;
   // the grid is then sized for the longest context and surplus splits leave at once.
-  const int last = pos_dev ? *KX_CKP(AB_POS, pos_dev) : last_val;
+  // `last`: rows the cut and the loads go by; `seen`: the last row that counts.
+  int last, seen;
+  if constexpr (STATIC) {
+    // a VECTOR load: a uniform address would be fetched through the scalar cache, and scalar loads
+    // are waited for all together (lgkmcnt(0)) with the kernel arguments, ahead of everything else;
+    // the lane-dependent zero hides the uniformity
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    seen = *KX_CKP(AB_POS, pos_dev + lane_zero);
+    last = last_val;
+  } else {
+    last = pos_dev ? *KX_CKP(AB_POS, pos_dev) : last_val;
+    seen = last;
+  }
   const int ntiles = (last >> 4) + 1;
-  const AttnSplit cut = attn_split(ntiles, (int)gridDim.y, (int)gridDim.x, sizeof(KVT) == 4, NW);
+  const AttnSplit cut = attn_split(ntiles, grid_splits, grid_kvh, sizeof(KVT) == 4, NW);
   const int nsplit = cut.nsplit;
   if (split >= nsplit) return;
   const KVT* kbase = kc + (size_t)kvh * HS;
@@ -335,18 +355,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
           sv[r] = xor16_sum(sv[r]);
           sv[r] = xor32_sum(sv[r]);
           sv[r] *= scale;
-          if (key0 + 4 * kb + r > last) sv[r] = -INFINITY;
+          if (key0 + 4 * kb + r > seen) sv[r] = -INFINITY;
         }
         // every lane (any qd, kb) of head hd ends up with the head's maximum over the 16 keys
         float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
         mx = fmaxf(mx, dpp_mov<0x124>(mx));  // row_ror:4 -> the next key block, same head
         mx = fmaxf(mx, dpp_mov<0x128>(mx));  // row_ror:8
         const float m_new = fmaxf(m_run[gi], mx);
-        const float alpha = fast_exp(m_run[gi] - m_new);  // first tile: exp(-inf) = 0
+        // STATIC: a tile wholly above the position leaves the maximum at -inf; subtracting 0
+        // instead keeps every factor at exp(-inf) = 0
+        const float m_sub = STATIC && m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = fast_exp(m_run[gi] - m_sub);  // first tile: exp(-inf) = 0
         m_run[gi] = m_new;
         float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = fast_exp(sv[r] - m_new);
+        for (int r = 0; r < 4; ++r) pv[r] = fast_exp(sv[r] - m_sub);
         l_run[gi] = l_run[gi] * alpha + ((pv[0] + pv[1]) + (pv[2] + pv[3]));  // this lane's 4 keys
         // P[key][head] -> LDS as [parity][head][step], key = 2 step + parity, so that a lane of
         // the second product reads the 8 probabilities it needs as two 16-byte words
@@ -455,16 +478,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
                    (s0.w + s1.w) * scale};
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (key0 + 4 * g + r > last) sv[r] = -INFINITY;
+      if (key0 + 4 * g + r > seen) sv[r] = -INFINITY;
     float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
     mx = xor16_max(mx);
     mx = xor32_max(mx);
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = fast_exp(m_run - m_new);  // first tile: exp(-inf) = 0
+    const float m_sub = STATIC && m_new == -INFINITY ? 0.f : m_new;  // see the 4x4x1 form
+    const float alpha = fast_exp(m_run - m_sub);  // first tile: exp(-inf) = 0
     m_run = m_new;
     float p[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = fast_exp(sv[r] - m_new);
+    for (int r = 0; r < 4; ++r) p[r] = fast_exp(sv[r] - m_sub);
     l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
     // The output tile keeps the head on the lane (column), so alpha is lane-local.
 #pragma unroll
@@ -532,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
     } else {
       // write-through (device-scope) stores: visible to the merging workgroup on any XCD without
       // a cache write-back
-      float* dst = ws + ((size_t)hq * gridDim.y + split) * attn_ws_stride(HS);
+      float* dst = ws + ((size_t)hq * grid_splits + split) * attn_ws_stride(HS);
       if (d == 0) {
         st_device(KX_CKP(AB_WS, dst + HS), M);
         st_device(KX_CKP(AB_WS, dst + HS + 1), L);
@@ -568,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
   __syncthreads();
   stamp(4);  // ticket drawn
   if (!sm_last) {
-    attn_touch_next(next, split * (int)gridDim.x + kvh, nsplit * (int)gridDim.x KX_BFWD);
+    attn_touch_next(next, split * grid_kvh + kvh, nsplit * grid_kvh KX_BFWD);
     return;
   }
   // Every byte another workgroup wrote is read below with a device-scope (sc1) load, which goes
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
   float* sf = sm_sf + wave * kMaxSplits;  // this wave's split weights
   for (int head = wave; head < kv_mul; head += kAttnWaves) {
     // byte offset of this head's partials in the workspace (a few MiB at most)
-    const unsigned base = (unsigned)((kvh * kv_mul + head) * gridDim.y * stride) * 4u;
+    const unsigned base = (unsigned)((kvh * kv_mul + head) * grid_splits * stride) * 4u;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < nsplit; s0 += PASS * RG) {
       f32x4 ov[PASS];
@@ -708,7 +732,8 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
                              float* out, int32_t pos, const int32_t* pos_dev, int32_t head_num,
                              int32_t kv_mul, int32_t head_size, int32_t kv_dim, int32_t seq_len,
                              int32_t layer_index, void* workspace, size_t workspace_bytes,
-                             void* stream, const kx::AttnNext* next_or_null = nullptr) {
+                             void* stream, const kx::AttnNext* next_or_null = nullptr,
+                             bool rows_to_pos_readable = false) {
   using namespace kx;
   if (!query || !key_cache || !value_cache || !out) return KX_EINVAL;
   const AttnNext next = next_or_null ? *next_or_null : AttnNext{};
@@ -781,7 +806,10 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // a launch that reads its position from the device may see shorter contexts, for which the
   // finer cut is the better one (surplus workgroups leave at once).
   const AttnSplit cut = attn_split(ntiles, nsplit, kvh, kFp32Cache, nw);
-  if (!pos_dev) nsplit = cut.nsplit;
+  // the cut of `pos` itself, with the position read from the device as a mask only
+  static const bool no_fixed = getenv("KX_ATTN_NO_FIXED_CUT") != nullptr;  // A/B runs
+  const bool fixed_cut = pos_dev && rows_to_pos_readable && !no_fixed;
+  if (!pos_dev || fixed_cut) nsplit = cut.nsplit;
   unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
   float* ws = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketBytes) : nullptr;
   hipStream_t s = (hipStream_t)stream;
@@ -795,16 +823,16 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
       trace = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + used);
   }
   const bool prefetch = cut.longest() > nw;
-#define KX_ATTN_LAUNCH_NW(HS_, M4_, NW_)                                                          \
-  do {                                                                                           \
-    if (prefetch)                                                                                \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, true, KVT, M4_, NW_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace, next       \
-                         KX_BPASS(9, query, kc, vc, out, ws, tickets, pos_dev, next.p[0], next.p[1]));                        \
-    else                                                                                         \
-      hipLaunchKernelGGL((attn_decode_kernel<HS_, false, KVT, M4_, NW_>), grid, block, 0, s, query, kc, vc, \
-                         out, ws, tickets, pos, pos_dev, kv_mul, kv_dim, scale, trace, next       \
-                         KX_BPASS(9, query, kc, vc, out, ws, tickets, pos_dev, next.p[0], next.p[1]));                        \
+#define KX_ATTN_LAUNCH_ONE(HS_, PF_, M4_, NW_, ST_)                                                          \
+  hipLaunchKernelGGL((attn_decode_kernel<HS_, PF_, KVT, M4_, NW_, ST_>), grid, block, 0, s, query, kc, vc, out, \
+                     ws, tickets, pos, pos_dev, kvh, nsplit, kv_mul, kv_dim, scale, trace, next                  \
+                     KX_BPASS(9, query, kc, vc, out, ws, tickets, pos_dev, next.p[0], next.p[1]))
+#define KX_ATTN_LAUNCH_NW(HS_, M4_, NW_)                          \
+  do {                                                           \
+    if (prefetch && fixed_cut) KX_ATTN_LAUNCH_ONE(HS_, true, M4_, NW_, true);        \
+    else if (prefetch) KX_ATTN_LAUNCH_ONE(HS_, true, M4_, NW_, false);               \
+    else if (fixed_cut) KX_ATTN_LAUNCH_ONE(HS_, false, M4_, NW_, true);              \
+    else KX_ATTN_LAUNCH_ONE(HS_, false, M4_, NW_, false);                            \
   } while (0)
 #define KX_ATTN_LAUNCH(HS_, M4_) KX_ATTN_LAUNCH_NW(HS_, M4_, 4)
   switch (head_size) {
@@ -821,6 +849,7 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   }
 #undef KX_ATTN_LAUNCH
 #undef KX_ATTN_LAUNCH_NW
+#undef KX_ATTN_LAUNCH_ONE
   KX_LAUNCH_CHECK();
   return KX_OK;
 }
@@ -976,9 +1005,9 @@ static AttnNext attn_next_of(const void* p0, size_t bytes0, size_t gran0, const 
 }
 }  // namespace kx
 
-extern "C" int kx_mha_decode_dpos_touch_f32(const float* query, const float* key_cache,
+extern "C" int kx_mha_decode_dpos_ex_f32(const float* query, const float* key_cache,
                                             const float* value_cache, float* out,
-                                            const int32_t* pos_dev, int32_t max_pos, int32_t head_num,
+                                            const int32_t* pos_dev, int32_t max_pos, int32_t rows_to_max_pos_readable, int32_t head_num,
                                             int32_t kv_mul, int32_t head_size, int32_t kv_dim,
                                             int32_t seq_len, int32_t layer_index, void* workspace,
                                             size_t workspace_bytes, const void* next0,
@@ -988,7 +1017,7 @@ extern "C" int kx_mha_decode_dpos_touch_f32(const float* query, const float* key
   const kx::AttnNext nx = kx::attn_next_of(next0, next0_bytes, next0_granule, next1, next1_bytes, next1_granule);
   return mha_decode_launch<float>(query, key_cache, value_cache, out, max_pos, pos_dev, head_num, kv_mul,
                                   head_size, kv_dim, seq_len, layer_index, workspace, workspace_bytes,
-                                  stream, &nx);
+                                  stream, &nx, rows_to_max_pos_readable != 0);
 }
 
 extern "C" int kx_mha_decode_kv16(const float* query, const void* key_cache16,
@@ -1003,9 +1032,9 @@ extern "C" int kx_mha_decode_kv16(const float* query, const void* key_cache16,
                                      workspace, workspace_bytes, stream);
 }
 
-extern "C" int kx_mha_decode_kv16_touch(const float* query, const void* key_cache16,
+extern "C" int kx_mha_decode_kv16_ex(const float* query, const void* key_cache16,
                                         const void* value_cache16, float* out, int32_t pos,
-                                        const int32_t* pos_dev, int32_t head_num, int32_t kv_mul,
+                                        const int32_t* pos_dev, int32_t rows_to_pos_readable, int32_t head_num, int32_t kv_mul,
                                         int32_t head_size, int32_t kv_dim, int32_t seq_len,
                                         int32_t layer_index, void* workspace, size_t workspace_bytes,
                                         const void* next0, size_t next0_bytes, size_t next0_granule,
@@ -1015,5 +1044,5 @@ extern "C" int kx_mha_decode_kv16_touch(const float* query, const void* key_cach
   return mha_decode_launch<_Float16>(query, static_cast<const _Float16*>(key_cache16),
                                      static_cast<const _Float16*>(value_cache16), out, pos, pos_dev,
                                      head_num, kv_mul, head_size, kv_dim, seq_len, layer_index,
-                                     workspace, workspace_bytes, stream, &nx);
+                                     workspace, workspace_bytes, stream, &nx, rows_to_pos_readable != 0);
 }

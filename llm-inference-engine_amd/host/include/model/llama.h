@@ -226,6 +226,14 @@ class LlamaModel {
   size_t pf_bytes_ = 0;
 
   void* graph_ = nullptr;
+  // Upper bound of the position the step launches being issued will read from pos_dev_ (-1 = none:
+  // seq_len - 1, cut by the position itself): the decode attention is cut for the bound and reads
+  // the position as a mask only, so its cache addresses do not wait for it.  A step issued eagerly
+  // knows its position; a captured step serves kAttnSpan positions (graph_bound_: the last one)
+  // and is captured again past them, or when the context has become much shorter.
+  int32_t attn_bound_ = -1;
+  int32_t graph_bound_ = -1;
+  static constexpr int32_t kAttnSpan = 256;
 
   // reference-structured path
   struct RefLayers;

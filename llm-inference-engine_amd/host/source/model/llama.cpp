@@ -1,5 +1,6 @@
 #include "model/llama.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -856,6 +857,10 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
   if (all && !x_valid_) KX_RET(kx_embedding_dpos_f32(history_dev_, pos_dev_, emb_, c.dim, c.vocab_size, x_, st));
   x_valid_ = false;  // the layers overwrite it; classify_and_pick() makes it valid again
   const int32_t ql = c.q_dim_local, kl = c.kv_dim_local;
+  // the cache is zero-filled when it is made and rows only ever receive finite numbers: rows above
+  // the position may be read (with zero weight)
+  const int32_t attn_fixed = attn_bound_ >= 0 && attn_bound_ < c.seq_len;
+  const int32_t attn_bound = attn_fixed ? attn_bound_ : c.seq_len - 1;
   for (int32_t l = 0; l < c.layer_num; ++l) {
     const LayerWeights& lw = layers_[l];
     auto [k_ptr, v_ptr] = kv_->get_cache_ptr(l);
@@ -872,14 +877,14 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
       const size_t g0 = (size_t)rpb * lw.wo.cols, b1 = wo_bytes / c.group_size * sizeof(float),
                    g1 = g0 / c.group_size * sizeof(float);
       if (c.kv_f16)
-        KX_RET(kx_mha_decode_kv16_touch(q_, kv_->get_raw_buffer_k(), kv_->get_raw_buffer_v(), att_,
-                                        c.seq_len - 1, pos_dev_, c.head_local, c.kv_mul, c.head_size, kl,
+        KX_RET(kx_mha_decode_kv16_ex(q_, kv_->get_raw_buffer_k(), kv_->get_raw_buffer_v(), att_,
+                                        attn_bound, pos_dev_, attn_fixed, c.head_local, c.kv_mul, c.head_size, kl,
                                         c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes,
                                         n0, wo_bytes, g0, n1, b1, g1, st));
       else
-        KX_RET(kx_mha_decode_dpos_touch_f32(q_, static_cast<float*>(kv_->get_raw_buffer_k()),
+        KX_RET(kx_mha_decode_dpos_ex_f32(q_, static_cast<float*>(kv_->get_raw_buffer_k()),
                                             static_cast<float*>(kv_->get_raw_buffer_v()), att_, pos_dev_,
-                                            c.seq_len - 1, c.head_local, c.kv_mul, c.head_size, kl,
+                                            attn_bound, attn_fixed, c.head_local, c.kv_mul, c.head_size, kl,
                                             c.seq_len, l, hip_->attn_workspace, hip_->attn_workspace_bytes,
                                             n0, wo_bytes, g0, n1, b1, g1, st));
     }
@@ -959,7 +964,10 @@ base::Status LlamaModel::set_state(int32_t token, int32_t pos) {
 
 base::Status LlamaModel::step_logits(int32_t token, int32_t pos, float* logits_host) {
   ST_RET(set_state(token, pos));
-  ST_RET(launch_step(hip_->stream, true));
+  attn_bound_ = pos;
+  base::Status launched = launch_step(hip_->stream, true);
+  attn_bound_ = -1;
+  ST_RET(launched);
   ST_RET(gather_logits());
   KX_RET(kx_stream_sync(hip_->stream));
   if (logits_host) KX_RET(kx_memcpy_d2h(logits_host, logits_, (size_t)cfg_.vocab_size * 4, nullptr));
@@ -981,23 +989,48 @@ base::Status LlamaModel::decode(int32_t steps, bool use_graph) {
     KX_RET(kx_embedding_dpos_f32(history_dev_, pos_dev_, emb_, cfg_.dim, cfg_.vocab_size, x_, st));
     x_valid_ = true;
   }
-  if (use_graph) {
+  auto step_at = [&](int32_t at) {  // one eager step at a known position
+    attn_bound_ = at;
+    base::Status s = launch_step(st, true);
+    attn_bound_ = -1;
+    return s;
+  };
+  if (!use_graph) {
+    for (int32_t i = 0; i < steps; ++i) ST_RET(step_at(pos + i));
+    return base::error::Success();
+  }
+  const char* span_env = getenv("KX_ATTN_SPAN");  // tests and A/B runs
+  const int32_t span = span_env ? std::max(1, atoi(span_env)) : kAttnSpan;
+  while (steps > 0) {
+    // The captured step serves the positions up to graph_bound_ (its attention launches are cut
+    // for that row and read every row up to it); past them, or with a context that has become
+    // shorter by more than a span, the step is captured again.
+    if (graph_ && (pos > graph_bound_ || pos + 2 * span <= graph_bound_)) {
+      kx_graph_destroy(graph_);
+      graph_ = nullptr;
+    }
     if (!graph_) {
       // one eager step first: lazy per-kernel setup (e.g. raising a kernel's LDS limit) must
       // not happen while the stream is capturing
-      ST_RET(launch_step(st, true));
-      --steps;
+      ST_RET(step_at(pos));
+      ++pos;
+      if (--steps == 0) break;
+      const int32_t bound = std::min(pos + span - 1, cfg_.seq_len - 1);
       KX_RET(kx_graph_begin_capture(st));
+      attn_bound_ = bound;
       base::Status s = launch_step(st, true);
+      attn_bound_ = -1;
       void* g = nullptr;
       const int rc = kx_graph_end_capture(st, &g);
       if (!s) return s;
       KX_RET(rc);
       graph_ = g;
+      graph_bound_ = bound;
     }
-    for (int32_t i = 0; i < steps; ++i) KX_RET(kx_graph_launch(graph_, st));
-  } else {
-    for (int32_t i = 0; i < steps; ++i) ST_RET(launch_step(st, true));
+    const int32_t n = std::min(steps, graph_bound_ - pos + 1);
+    for (int32_t i = 0; i < n; ++i) KX_RET(kx_graph_launch(graph_, st));
+    steps -= n;
+    pos += n;
   }
   return base::error::Success();
 }
@@ -1010,7 +1043,12 @@ base::Status LlamaModel::prefill_sequential(const int32_t* tokens, int32_t n, in
   KX_RET(kx_memcpy_h2d(history_dev_ + pos0, tokens, (size_t)n * 4, nullptr));
   KX_RET(kx_memcpy_h2d(pos_dev_, &pos0, 4, nullptr));
   x_valid_ = false;
-  for (int32_t i = 0; i < n; ++i) ST_RET(launch_step(hip_->stream, false));
+  for (int32_t i = 0; i < n; ++i) {
+    attn_bound_ = pos0 + i;
+    base::Status s = launch_step(hip_->stream, false);
+    attn_bound_ = -1;
+    ST_RET(s);
+  }
   ST_RET(gather_logits());
   KX_RET(kx_stream_sync(hip_->stream));
   // leave the state ready for decode(): the sampled token of the last prompt row

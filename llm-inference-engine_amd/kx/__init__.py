@@ -111,10 +111,10 @@ SIGNATURES = {
                                            _i32, _vp]),
     "kx_mha_decode_dpos_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                          _i32, _i32, _vp, _sz, _vp]),
-    "kx_mha_decode_dpos_touch_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+    "kx_mha_decode_dpos_ex_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                                _i32, _i32, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp]),
     "kx_gemv_w8_block_rows": (_i32, [_i32, _i32, _i32]),
-    "kx_mha_decode_kv16_touch": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+    "kx_mha_decode_kv16_ex": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                            _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp]),
     "kx_flash_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _i32, _f, _i32, _vp, _sz, _vp]),

@@ -356,12 +356,15 @@ def test_mha_decode_device_position_one_workspace_many_launches():
 
 @pytest.mark.parametrize("H,KVH,hs,S,K,M", [(32, 8, 128, 4736, 4096, 4096), (32, 8, 128, 2304, 4000, 4096),
                                             (6, 2, 64, 1200, 1536, 384), (16, 2, 128, 4500, 2048, 2048)])
-def test_mha_decode_that_warms_the_next_launch_gives_the_same_bits(H, KVH, hs, S, K, M, monkeypatch):
-    # the touching entries read the head of the granules of a following K x M GEMV (int8 rows and
-    # scales, buffers of exactly that size: the bounds-checking build sees every touched address)
-    # and change nothing: same bits as the plain entry, workspace tickets at zero, the touched
-    # buffers untouched; a ragged last granule, a range that is not whole lines, a null range,
-    # a share of 100 %, a single split and the 16-bit cache form included
+def test_mha_decode_with_hints(H, KVH, hs, S, K, M, monkeypatch):
+    # the hinted entries (1) read the head of the granules of a following K x M GEMV (int8 rows and
+    # scales, buffers of exactly that size: the bounds-checking build sees every touched address):
+    # same bits as the plain entry, workspace tickets at zero, the touched buffers untouched; a
+    # ragged last granule, a range that is not whole lines, a null range, a share of 100 %, a single
+    # split and the 16-bit cache form included; (2) cut the launch for an upper bound of the
+    # position and use the position as a mask only: the rows between the two are read with zero
+    # weight (here they hold other random rows), bounds right at the position, a tile and many
+    # tiles above it, whole splits masked out -- against the plain entry's result
     rng = np.random.default_rng(S + K)
     kvd = KVH * hs
     kc = rng.standard_normal((1, S, kvd)).astype(np.float32)
@@ -391,14 +394,15 @@ def test_mha_decode_that_warms_the_next_launch_gives_the_same_bits(H, KVH, hs, S
         kx.sync()
         return out.numpy()
 
-    def touching(pos, half, n0, b0, gr0, n1, b1, gr1):
+    def touching(pos, half, n0, b0, gr0, n1, b1, gr1, bound=None):
         out = kx.Buf.zeros(H * hs)
+        top, fixed = (S - 1, 0) if bound is None else (bound, 1)
         if half:
-            kx.check(L.kx_mha_decode_kv16_touch(dq.ptr, dk16.ptr, dv16.ptr, out.ptr, S - 1, pos_dev.ptr, H, H // KVH,
-                                                hs, kvd, S, 0, ws.ptr, wsb, n0, b0, gr0, n1, b1, gr1, None))
+            kx.check(L.kx_mha_decode_kv16_ex(dq.ptr, dk16.ptr, dv16.ptr, out.ptr, top, pos_dev.ptr, fixed, H,
+                                             H // KVH, hs, kvd, S, 0, ws.ptr, wsb, n0, b0, gr0, n1, b1, gr1, None))
         else:
-            kx.check(L.kx_mha_decode_dpos_touch_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, S - 1, H, H // KVH,
-                                                    hs, kvd, S, 0, ws.ptr, wsb, n0, b0, gr0, n1, b1, gr1, None))
+            kx.check(L.kx_mha_decode_dpos_ex_f32(dq.ptr, dk.ptr, dv.ptr, out.ptr, pos_dev.ptr, top, fixed, H,
+                                                 H // KVH, hs, kvd, S, 0, ws.ptr, wsb, n0, b0, gr0, n1, b1, gr1, None))
         kx.sync()
         return out.numpy()
 
@@ -416,6 +420,9 @@ def test_mha_decode_that_warms_the_next_launch_gives_the_same_bits(H, KVH, hs, S
                     monkeypatch.delenv("KX_ATTN_TOUCH_PCT", raising=False)
                 assert np.array_equal(touching(pos, half, dw.ptr, K * M, g0, dsc.ptr, sc.nbytes, g1), base)
             monkeypatch.delenv("KX_ATTN_TOUCH_PCT", raising=False)
+            for bound in sorted({pos, min(pos + 1, S - 1), min(pos + 16, S - 1), min(pos + 255, S - 1), S - 1}):
+                got = touching(pos, half, dw.ptr, K * M, g0, dsc.ptr, sc.nbytes, g1, bound)
+                np.testing.assert_allclose(got, base, rtol=0, atol=2e-5, err_msg=f"pos={pos} half={half} bound={bound}")
             # one range only; a range that is not whole lines (ignored); granules that do not divide the range
             assert np.array_equal(touching(pos, half, None, 0, 0, dsc.ptr, sc.nbytes, g1), base)
             assert np.array_equal(touching(pos, half, dw.ptr, K * M - 64, g0, None, 0, 0), base)

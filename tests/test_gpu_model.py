@@ -139,6 +139,37 @@ def test_tiny_q8_prefill_then_graph_decode_token_exact(golden, golden_bytes, exa
         np.testing.assert_allclose(v, ov_[layer, :n], rtol=0, atol=tol * np.abs(ov_[layer, :n]).max())
 
 
+def test_captured_step_is_renewed_past_its_attention_bound(monkeypatch):
+    # the captured step's attention launches are cut for an upper bound of the position (the
+    # position itself only masks) and serve a span of positions; past the bound, or when the
+    # context has become much shorter, the step is captured again.  Spans of 8 and 1 position,
+    # several decode calls, a reset to a shorter context and one to a longer one: the same tokens
+    # as steps issued one by one, whose launches are cut for their exact position.  Split contexts
+    # (160+ keys: several workgroups per kv head) included.
+    shape = dict(dim=256, hidden_dim=512, layer_num=2, head_num=4, kv_head_num=2, vocab_size=500,
+                 rope_variant=1, rope_theta=5e5, rms_eps=1e-5)
+    rng = np.random.default_rng(5)
+    long_prompt = rng.integers(0, 500, 150).astype(np.int32)
+    short_prompt = rng.integers(0, 500, 9).astype(np.int32)
+    eager = host.Model(seq_len=400, group_size=GS, **shape)
+    eager.init_synthetic(3)
+    for span in ("8", "1", "64"):
+        monkeypatch.setenv("KX_ATTN_SPAN", span)
+        m = host.Model(seq_len=400, group_size=GS, **shape)
+        m.init_synthetic(3)
+        for prompt, calls in ((long_prompt, (3, 30, 1, 40)), (short_prompt, (25, 2)), (long_prompt, (100,))):
+            m.prefill(prompt, exact=True)
+            eager.prefill(prompt, exact=True)
+            for n in calls:
+                m.decode(n, use_graph=True)
+                eager.decode(n, use_graph=False)
+                assert m.state() == eager.state(), (span, len(prompt), n)
+            total = len(prompt) + sum(calls)
+            assert m.history(total + 1).tolist() == eager.history(total + 1).tolist(), (span, len(prompt))
+        m.close()
+    eager.close()
+
+
 # ---------------- half-split RoPE families: fixtures written by the reference's HF exporters -------
 # g6 / g7 (tests/golden/make_golden_hf.py): files from tools/export_llama3.py / export_qwen2.py,
 # expected logits and greedy streams computed by the Hugging Face models themselves.
