@@ -534,6 +534,18 @@ int kx_decode_step_end_embed(const float* logits, int32_t n, int32_t* token_dev,
                              int32_t* history_dev, int32_t history_len, int32_t write_history,
                              const float* table, int32_t dim, int32_t vocab_size, float* x_out,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* The classifier GEMV and kx_decode_step_end_embed as ONE launch (the reference runs cls_layer
+ * forward and the argmax sampler as separate steps, llama3.cpp:155-175 / argmax_sampler.cpp:6-8):
+ * `d` describes the product (mode KX_GEMV_PLAIN, no row routing, no residual; norm_w allowed) and
+ * its logits are written to d->y0 as by kx_gemv_w8_fused_f32; every workgroup keeps the best of the
+ * rows it finishes and the last one to arrive picks, does the bookkeeping and leaves the next
+ * embedding row -- x_out may be d->x.  Same results as the two calls, bit for bit.  The workspace
+ * is the step workspace (zero before first use).  KX_EUNSUPPORTED for shapes the fast GEMV form does
+ * not take or with more workgroups than pair slots: run the two calls then. */
+int kx_gemv_w8_classify_pick_f32(const kx_gemv_w8_desc* d, int32_t* token_dev, int32_t* pos_dev,
+                                 int32_t* history_dev, int32_t history_len, int32_t write_history,
+                                 const float* table, int32_t dim, int32_t vocab_size, float* x_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same step end for a classifier whose rows are split over tensor-parallel ranks (no
  * reference counterpart: the reference never shards, nccl_handler.cpp:60-80).  Each rank turns its

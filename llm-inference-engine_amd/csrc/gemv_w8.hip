@@ -25,6 +25,7 @@
 // products x*w of a lane are summed first and the group scale multiplies that partial sum.
 #include <algorithm>
 #include "gemv_w8.hpp"
+#include "kx_step.hpp"
 
 namespace kx {
 
@@ -293,10 +294,11 @@ __device__ __forceinline__ void consume(const GemvW8Args& a, const f32x4* xs, in
 }
 
 // Wave reduction and epilogue of R finished rows.
-template <int R, int MODE>
+// PICK: lane 0 also keeps the largest finished value and its row (first maximum wins)
+template <int R, int MODE, bool PICK = false>
 __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row_end, int pos,
                                             float rs, int lane,
-                                            GemvRows<R, MODE == GEMV_GATE_UP>& S) {
+                                            GemvRows<R, MODE == GEMV_GATE_UP>& S, float& best, int& bi) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     S.total[r] = wave_sum(S.total[r]) * rs;
@@ -334,7 +336,9 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
         int rr;
         [[maybe_unused]] int op;
         route(a, row, 0, dst, rr, op);
-        *KX_CK(a, op, dst + rr) = S.total[r] + (S.bias[r] + S.residual[r]);
+        const float v = S.total[r] + (S.bias[r] + S.residual[r]);
+        *KX_CK(a, op, dst + rr) = v;
+        if constexpr (PICK) argmax_merge(best, bi, v, row);
       }
     }
   }
@@ -342,8 +346,8 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
 
 // R rows per wave at a time (R even for GEMV_QKV_ROPE), U chunk loads per row in flight.
 // For shapes where a wave gets a single batch (or a few).
-template <int R, int U, int MODE>
-__global__ void gemv_w8_kernel(const GemvW8Args a) {
+template <int R, int U, int MODE, bool PICK = false>
+__device__ __forceinline__ void gemv_w8_body(const GemvW8Args& a, float& best, int& bi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* xs = reinterpret_cast<f32x4*>(smem);
   __shared__ float red[16];
@@ -389,7 +393,7 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
                                                     B.sc2);
       consume<R, U, MODE>(a, xs, lane, c0, B, S);
     }
-    finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
+    finish_rows<R, MODE, PICK>(a, r0, row_end, pos, rs, lane, S, best, bi);
     r0 += nwaves * R;
   }
   bool staged = kPeelFirst;
@@ -414,8 +418,57 @@ __global__ void gemv_w8_kernel(const GemvW8Args a) {
       }
       consume<R, U, MODE>(a, xs, lane, c0, B, S);
     }
-    finish_rows<R, MODE>(a, r0, row_end, pos, rs, lane, S);
+    finish_rows<R, MODE, PICK>(a, r0, row_end, pos, rs, lane, S, best, bi);
   }
+}
+
+template <int R, int U, int MODE>
+__global__ void gemv_w8_kernel(const GemvW8Args a) {
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  gemv_w8_body<R, U, MODE>(a, best, bi);
+}
+
+// The classifier GEMV that also ends the decode step (step_pick_kernel's work without its launch
+// and without reading the logits back): lane 0 of every wave keeps the best of the rows it
+// finished, the workgroup's best pair goes out with write-through stores, an arrival ticket follows,
+// and the workgroup that draws the last ticket merges all pairs, does the step's bookkeeping and
+// leaves the next step's embedding row -- which may be this GEMV's own input vector: every other
+// workgroup has drawn its ticket, i.e. is done with x, by then.
+template <int R, int U>
+__global__ void gemv_w8_pick_kernel(const GemvW8Args a, const StepArgs st) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  __shared__ int sm_last, sm_tok;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  gemv_w8_body<R, U, GEMV_PLAIN, true>(a, best, bi);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) {
+    sv[wave] = best;
+    si[wave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
+    __hip_atomic_store(KX_CK(st, SB_PV, st.pv + blockIdx.x), best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(KX_CK(st, SB_PI, st.pi + blockIdx.x), bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both stores (and this thread's logits) acknowledged before the ticket
+    sm_last = atomicInc(KX_CK(st, SB_TICKET, st.ticket), gridDim.x - 1u) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!sm_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler order only: the loads below are device-scope
+  best = -INFINITY;
+  bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+    argmax_merge(best, bi, __hip_atomic_load(KX_CK(st, SB_PV, st.pv + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                 __hip_atomic_load(KX_CK(st, SB_PI, st.pi + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();  // sv / si are reused
+  block_argmax(best, bi, sv, si);
+  if (threadIdx.x == 0) step_bookkeeping(st, bi, &sm_tok);
+  __syncthreads();
+  step_embed(st, sm_tok);
 }
 
 // Any M % 4 == 0 and any group size, groups may straddle rows: one wave per row, 4 elements
@@ -511,13 +564,27 @@ static GemvGeometry gemv_geometry(int mode, int M, int out_rows) {
   return GemvGeometry{threads, R, rpb, tall_x};
 }
 
+template <int R, int U>
+static int launch_pick(const GemvW8Args& a, const StepArgs& st, int threads, hipStream_t s) {
+  const int grid = (a.K + a.rows_per_block - 1) / a.rows_per_block;
+  if (grid > kStepSlots) return KX_EUNSUPPORTED;  // one pair slot per workgroup
+  const size_t lds = (size_t)a.chunks * 1024 * sizeof(float);
+  if (lds > 64 * 1024) {
+    static OncePerDevice raised;  // per instantiation; the attribute is sticky
+    if (int rc = raised.raise(reinterpret_cast<const void*>(&gemv_w8_pick_kernel<R, U>), 160 * 1024 - 64)) return rc;
+  }
+  hipLaunchKernelGGL((gemv_w8_pick_kernel<R, U>), dim3(grid), dim3(threads), lds, s, a, st);
+  KX_LAUNCH_CHECK();
+  return KX_OK;
+}
+
 static int ilog2(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
   return s;
 }
 
-int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) {
+int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s, const StepArgs* pick) {
   if (!a.x || !a.w || !a.scales || !a.y0) return KX_EINVAL;
   if (a.M <= 0 || a.K <= 0 || group_size <= 0) return KX_EINVAL;
   if (a.M % 4 != 0) return KX_EINVAL;  // matmul_kernel.cu:123
@@ -531,6 +598,7 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
                     ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) &&
                     (!a.norm_w || (uintptr_t)a.norm_w % 16 == 0) &&
                     (size_t)((a.M + 1023) / 1024) * 4096 <= 160 * 1024 - 64;
+  if (pick && (!fast || mode != GEMV_PLAIN || a.k0 != a.K)) return KX_EUNSUPPORTED;
   if (!fast) {
     if (mode != GEMV_PLAIN || a.norm_w) return KX_EUNSUPPORTED;
     const int wpb = 4;
@@ -557,6 +625,10 @@ int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s) 
       if (a.K % 2 || a.k0 % 2 || a.k1 % 2 || a.head_size % 2) return KX_EINVAL;
       return launch<2, 2, GEMV_QKV_ROPE>(a, threads, s);
     default:
+      if (pick) {
+        if (tall_x) return launch_pick<1, 4>(a, *pick, threads, s);
+        return a.chunks <= 2 ? launch_pick<4, 2>(a, *pick, threads, s) : launch_pick<2, 4>(a, *pick, threads, s);
+      }
       if (tall_x) return launch<1, 4, GEMV_PLAIN>(a, threads, s);
       return a.chunks <= 2 ? launch<4, 2, GEMV_PLAIN>(a, threads, s)
                            : launch<2, 4, GEMV_PLAIN>(a, threads, s);
@@ -641,4 +713,35 @@ extern "C" int kx_gemv_w8_fused_f32(const kx_gemv_w8_desc* d, void* stream) {
   if (k0 < 0 || k1 < k0 || k1 > d->K) return KX_EINVAL;
   a.k0 = k0; a.k1 = k1;
   return kx::gemv_w8_dispatch(a, d->group_size, d->mode, (hipStream_t)stream);
+}
+
+extern "C" int kx_gemv_w8_classify_pick_f32(const kx_gemv_w8_desc* d, int32_t* token_dev, int32_t* pos_dev,
+                                            int32_t* history_dev, int32_t history_len,
+                                            int32_t write_history, const float* table, int32_t dim,
+                                            int32_t vocab_size, float* x_out, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  if (!d || !token_dev || !pos_dev) return KX_EINVAL;
+  if (d->mode != KX_GEMV_PLAIN || d->residual || d->y1 || d->y2) return KX_EINVAL;
+  if (table && (!x_out || !history_dev || dim <= 0 || vocab_size <= 0)) return KX_EINVAL;
+  if (!workspace || workspace_bytes < kx::kStepWorkspaceBytes) return KX_EWORKSPACE;
+  kx::GemvW8Args a{};
+  a.x = d->x; a.w = d->w; a.scales = d->scales;
+  a.norm_w = d->norm_w; a.norm_eps = d->norm_eps;
+  a.M = d->M; a.K = d->K;
+  a.bias = d->bias;
+  a.y0 = a.y1 = a.y2 = d->y0;
+  a.k0 = a.k1 = d->K;
+  kx::StepArgs st{};
+  st.logits = d->y0; st.n = d->K;
+  st.pv = static_cast<float*>(workspace);
+  st.pi = reinterpret_cast<int32_t*>(st.pv + kx::kStepSlots);
+  st.ticket = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kx::kStepTicketOff);
+  st.token = token_dev; st.pos = pos_dev; st.history = history_dev; st.history_len = history_len;
+  st.write_history = write_history != 0;
+  st.table = table; st.dim = dim; st.vocab = vocab_size; st.x_out = x_out;
+  using namespace kx;
+  KX_BSET(st, SB_LOGITS, st.logits); KX_BSET(st, SB_PV, st.pv); KX_BSET(st, SB_PI, st.pi); KX_BSET(st, SB_TICKET, st.ticket);
+  KX_BSET(st, SB_CAND, nullptr); KX_BSET(st, SB_TOKEN, st.token); KX_BSET(st, SB_POS, st.pos);
+  KX_BSET(st, SB_HISTORY, st.history); KX_BSET(st, SB_TABLE, st.table); KX_BSET(st, SB_XOUT, st.x_out);
+  return kx::gemv_w8_dispatch(a, d->group_size, kx::GEMV_PLAIN, (hipStream_t)stream, &st);
 }

@@ -40,6 +40,8 @@ struct GemvW8Args {
 };
 enum GemvOperand { GB_X, GB_W, GB_S, GB_Y0, GB_Y1, GB_Y2, GB_BIAS, GB_RES, GB_NORM, GB_SIN, GB_COS, GB_POS };
 
-int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s);
+struct StepArgs;
+// pick: the launch also ends the decode step (plain form without row routing only)
+int gemv_w8_dispatch(GemvW8Args a, int32_t group_size, int mode, hipStream_t s, const StepArgs* pick = nullptr);
 
 }  // namespace kx

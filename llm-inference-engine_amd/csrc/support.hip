@@ -3,6 +3,7 @@
 // simple, vectorised and correct; the reference twins are cited per kernel.
 #define KX_FILE_ID 7
 #include "kx_common.hpp"
+#include "kx_step.hpp"
 
 namespace kx {
 
@@ -223,12 +224,6 @@ __global__ void embedding_dpos_kernel(const int32_t* __restrict__ history,
 }
 
 // argmax_kernel_fp32 (cuda/argmax_kernel.cu:49-71): first maximum wins.  Single workgroup.
-__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
-  if (ov > v || (ov == v && oi < i)) {
-    v = ov;
-    i = oi;
-  }
-}
 __global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out KX_BPARAM(2)) {
   __shared__ float sv[16];
   __shared__ int si[16];
@@ -264,67 +259,6 @@ __global__ void argmax_kernel(const float* __restrict__ x, int n, int32_t* out K
 // wins, argmax_sampler.cpp:6-8); history[pos+1] = next; token = next; pos += 1.
 // Stage 1: kStepBlocks workgroups each reduce a contiguous slice to one (value, index) pair.
 // Stage 2: one workgroup reduces the pairs and does the bookkeeping.
-constexpr int kStepBlocks = 128;
-
-__device__ __forceinline__ void block_argmax(float& best, int& bi, float* sv, int* si) {
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float ov = __shfl_xor(best, off);
-    const int oi = __shfl_xor(bi, off);
-    argmax_merge(best, bi, ov, oi);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if (lane == 0) {
-    sv[wave] = best;
-    si[wave] = bi;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-    for (int w = 1; w < nw; ++w) argmax_merge(best, bi, sv[w], si[w]);
-}
-
-// One launch for both stages.  Every workgroup publishes its pair with write-through stores and
-// draws an arrival ticket (the counter wraps back to zero on the last arrival, so a workspace
-// that was zero before its first use stays usable from launch to launch); the workgroup that
-// draws the last ticket reads all pairs with device-scope loads and finishes the step.  With a
-// table it also leaves the embedding row of the token at the NEW position (the one just picked,
-// or, when the history is not written, the prompt token already stored there) in x_out, which
-// is the input of the next step.
-struct StepArgs {
-  const float* logits; int n;
-  float* pv; int32_t* pi; unsigned* ticket;
-  int index_base; float* cand;                    // candidate form: {value, global index} and no bookkeeping
-  int32_t* token; int32_t* pos; int32_t* history; int history_len; int write_history;
-  const float* table; int dim; int vocab; float* x_out;
-  KX_BFIELD(10)  // operands of the bounds-checking build, in the order of StepOperand
-};
-enum StepOperand { SB_LOGITS, SB_PV, SB_PI, SB_TICKET, SB_CAND, SB_TOKEN, SB_POS, SB_HISTORY, SB_TABLE, SB_XOUT };
-
-__device__ __forceinline__ void step_bookkeeping(const StepArgs& a, int bi, int* sm_tok) {
-  // thread 0 only
-  if (bi == 0x7fffffff) bi = 0;
-  const int p = *KX_CK(a, SB_POS, a.pos);
-  if (a.history && a.write_history && p + 1 < a.history_len) *KX_CK(a, SB_HISTORY, a.history + (p + 1)) = bi;
-  *KX_CK(a, SB_TOKEN, a.token) = bi;
-  *a.pos = p + 1;
-  int nxt = -1;
-  if (a.table && a.x_out && a.history && p + 1 < a.history_len)
-    nxt = a.write_history ? bi : *KX_CK(a, SB_HISTORY, a.history + (p + 1));
-  *sm_tok = nxt;
-}
-
-__device__ __forceinline__ void step_embed(const StepArgs& a, int tok) {
-  // whole workgroup; tok < 0: nothing to do
-  if (tok < 0) return;
-  if (tok >= a.vocab) tok = 0;
-  const float* src = a.table + (size_t)tok * a.dim;
-  if (a.dim % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)a.x_out % 16 == 0)) {
-    for (int i = threadIdx.x; i < a.dim / 4; i += blockDim.x)
-      *KX_CK(a, SB_XOUT, reinterpret_cast<f32x4*>(a.x_out) + i) = *KX_CK(a, SB_TABLE, reinterpret_cast<const f32x4*>(src) + i);
-  } else {
-    for (int i = threadIdx.x; i < a.dim; i += blockDim.x) *KX_CK(a, SB_XOUT, a.x_out + i) = *KX_CK(a, SB_TABLE, src + i);
-  }
-}
-
 __global__ __launch_bounds__(256) void step_pick_kernel(const StepArgs a) {
   __shared__ float sv[4];
   __shared__ int si[4];
@@ -588,15 +522,13 @@ extern "C" int kx_argmax_f32(const float* logits, int32_t n, int32_t* out_index,
   return KX_OK;
 }
 
-// pairs of the first stage, then the arrival ticket in a 256-byte block of its own
-constexpr size_t kStepTicketOff = kStepBlocks * 8;
-extern "C" size_t kx_step_workspace_bytes(void) { return kStepTicketOff + 256; }
+extern "C" size_t kx_step_workspace_bytes(void) { return kx::kStepWorkspaceBytes; }
 
 static int step_pick_launch(kx::StepArgs a, void* workspace, size_t workspace_bytes, void* stream) {
   if (!workspace || workspace_bytes < kx_step_workspace_bytes()) return KX_EWORKSPACE;
   a.pv = static_cast<float*>(workspace);
-  a.pi = reinterpret_cast<int32_t*>(a.pv + kx::kStepBlocks);
-  a.ticket = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kStepTicketOff);
+  a.pi = reinterpret_cast<int32_t*>(a.pv + kx::kStepSlots);
+  a.ticket = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kx::kStepTicketOff);
   const int blocks = a.n < kx::kStepBlocks * 256 ? (a.n + 255) / 256 : kx::kStepBlocks;
   KX_BSET(a, SB_LOGITS, a.logits); KX_BSET(a, SB_PV, a.pv); KX_BSET(a, SB_PI, a.pi); KX_BSET(a, SB_TICKET, a.ticket);
   KX_BSET(a, SB_CAND, a.cand); KX_BSET(a, SB_TOKEN, a.token); KX_BSET(a, SB_POS, a.pos);

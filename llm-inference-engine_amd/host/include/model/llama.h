@@ -232,6 +232,7 @@ class LlamaModel {
   // knows its position; a captured step serves kAttnSpan positions (graph_bound_: the last one)
   // and is captured again past them, or when the context has become much shorter.
   int32_t attn_bound_ = -1;
+  bool pick_unfused_ = false;  // the classifier's shape does not take the launch that also ends the step
   int32_t graph_bound_ = -1;
   static constexpr int32_t kAttnSpan = 256;
 

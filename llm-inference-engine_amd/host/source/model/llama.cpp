@@ -905,13 +905,40 @@ base::Status LlamaModel::launch_step(void* st, bool sample) {
 base::Status LlamaModel::classify_and_pick(const float* x_row, bool write_history, void* st) {
   const TransformerConfig& c = cfg_;
   float* local = logits_ + c.vocab_row0;
-  ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_row, final_norm_, local, nullptr, nullptr, 0, 0, nullptr, st));
   // the step's last launch also gathers the next step's input row: emb[history[pos + 1]]
   const bool embed = quant_ && !prof_on_;
   const float* table = embed ? emb_ : nullptr;
+  const bool one_rank_route = !c.cls_split && !(comm_ready_ && c.tp_size == 1);
+  if (one_rank_route && !pick_unfused_ && getenv("KX_NO_PICK_FUSE") == nullptr) {  // (the variable: A/B runs)
+    // classifier GEMV, greedy pick, bookkeeping and the next embedding row as one launch; shapes
+    // it does not take fall through to the separate launches for good
+    kx_gemv_w8_desc d{};
+    d.mode = KX_GEMV_PLAIN;
+    d.group_size = c.group_size;
+    d.M = cls_.cols;
+    d.K = cls_.rows;
+    d.x = x_row;
+    d.w = static_cast<const int8_t*>(cls_.w);
+    d.scales = cls_.s;
+    d.norm_w = final_norm_;
+    d.norm_eps = c.rms_eps;
+    d.y0 = local;
+    d.k0 = d.k1 = cls_.rows;
+    d.bias = cls_.bias;
+    const int rc = kx_gemv_w8_classify_pick_f32(&d, token_dev_, pos_dev_, history_dev_, c.seq_len + 1, write_history,
+                                                table, c.dim, c.vocab_size, x_, step_ws_,
+                                                kx_step_workspace_bytes(), st);
+    if (rc == KX_OK) {
+      x_valid_ = embed;
+      return base::error::Success();
+    }
+    if (rc != KX_EUNSUPPORTED) KX_RET(rc);
+    pick_unfused_ = true;
+  }
+  ST_RET(gemv(cls_, KX_GEMV_PLAIN, x_row, final_norm_, local, nullptr, nullptr, 0, 0, nullptr, st));
   // a communicator of one rank takes the candidate route too, so that route (its extra launches
   // and its collective) can be exercised, graph capture included, on a single GPU
-  if (!c.cls_split && !(comm_ready_ && c.tp_size == 1)) {
+  if (one_rank_route) {
     KX_RET(kx_decode_step_end_embed(local, c.vocab_local, token_dev_, pos_dev_, history_dev_, c.seq_len + 1,
                                     write_history, table, c.dim, c.vocab_size, x_, step_ws_,
                                     kx_step_workspace_bytes(), st));

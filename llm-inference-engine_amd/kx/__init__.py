@@ -142,6 +142,7 @@ SIGNATURES = {
     "kx_step_workspace_bytes": (_sz, []),
     "kx_decode_step_end": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "kx_gemv_w8_fused_f32": (C.c_int, [_vp, _vp]),
+    "kx_gemv_w8_classify_pick_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "kx_decode_step_end_embed": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "kx_argmax_candidate_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "kx_decode_step_end_candidates_embed": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),

@@ -658,6 +658,68 @@ def test_step_end_in_one_launch_with_the_next_embedding():
     assert L.kx_decode_step_end(dl.ptr, n, tok.ptr, pos.ptr, None, 0, ws.ptr, 64, None) == -3
 
 
+@pytest.mark.parametrize("K,M,tie", [(128256, 512, False), (5000, 2048, True), (3001 * 2, 4096, False), (640, 1024, True)])
+def test_classifier_gemv_that_ends_the_step(K, M, tie):
+    # one launch = classifier GEMV (RMS norm of x included) + greedy pick + bookkeeping + next
+    # embedding row, x_out being the GEMV's own input: logits, token, position, history and x_out
+    # equal to those of the two separate launches bit for bit; all three kernel forms (4 / 2 / 1 rows
+    # per wave), ties across workgroups (lowest row wins), a prompt row (history kept), and a shape
+    # the fast GEMV form does not take (refused: the caller runs the two launches)
+    rng = np.random.default_rng(K + M)
+    L = kx.lib()
+    _, w, s = rand_w8(rng, K, M)
+    if tie:
+        w[K - 3] = w[7]
+        s.reshape(K, M // GS)[K - 3] = s.reshape(K, M // GS)[7]
+    x0 = rng.standard_normal(M).astype(np.float32)
+    nw = rng.uniform(0.5, 1.5, M).astype(np.float32)
+    table = rng.standard_normal((K, M)).astype(np.float32) if K * M <= 64e6 else None
+    dw, dsc, dn = kx.Buf.from_numpy(w), kx.Buf.from_numpy(s), kx.Buf.from_numpy(nw)
+    dt = kx.Buf.from_numpy(table) if table is not None else None
+    ws = kx.Buf.zeros(L.kx_step_workspace_bytes(), np.uint8)
+    hist_len = 16
+
+    def run(fused, write):
+        x = kx.Buf.from_numpy(x0)
+        y = kx.Buf.zeros(K)
+        tok, pos = kx.Buf.zeros(1, np.int32), kx.Buf.from_numpy(np.array([4], np.int32))
+        hist = kx.Buf.from_numpy((np.arange(hist_len) * 37 % K).astype(np.int32))
+        d = kx.make_gemv_desc(0, x.ptr, dw.ptr, dsc.ptr, y.ptr, M, K, GS, norm_w=dn.ptr, k0=K, k1=K)
+        tp = dt.ptr if dt else None
+        if fused:
+            rc = L.kx_gemv_w8_classify_pick_f32(C.byref(d), tok.ptr, pos.ptr, hist.ptr, hist_len, write, tp, M, K,
+                                                x.ptr if dt else None, ws.ptr, ws.nbytes, None)
+            if rc != 0:
+                return rc
+        else:
+            kx.check(L.kx_gemv_w8_fused_f32(C.byref(d), None))
+            kx.check(L.kx_decode_step_end_embed(y.ptr, K, tok.ptr, pos.ptr, hist.ptr, hist_len, write, tp, M, K,
+                                                x.ptr if dt else None, ws.ptr, ws.nbytes, None))
+        kx.sync()
+        assert not ws.numpy(np.uint8, (ws.nbytes,))[-256:].any()
+        return y.numpy(), int(tok.numpy()[0]), int(pos.numpy()[0]), hist.numpy(), x.numpy()
+
+    for write in (1, 0, 1):
+        a, b = run(True, write), run(False, write)
+        assert np.array_equal(a[0], b[0]) and a[1:3] == b[1:3]
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert a[1] == kxo.argmax(a[0]) and a[2] == 5
+        if tie:
+            assert a[0][7] == a[0][K - 3]
+    # preconditions: routed rows and a residual are refused
+    x, y = kx.Buf.from_numpy(x0), kx.Buf.zeros(K)
+    tok, pos = kx.Buf.zeros(1, np.int32), kx.Buf.zeros(1, np.int32)
+    d = kx.make_gemv_desc(0, x.ptr, dw.ptr, dsc.ptr, y.ptr, M, K, GS, residual=y.ptr, k0=K, k1=K)
+    assert L.kx_gemv_w8_classify_pick_f32(C.byref(d), tok.ptr, pos.ptr, None, 0, 1, None, 0, 0, None, ws.ptr,
+                                          ws.nbytes, None) == -1
+    d = kx.make_gemv_desc(0, x.ptr, dw.ptr, dsc.ptr, y.ptr, M, K, GS, k0=K, k1=K)
+    assert L.kx_gemv_w8_classify_pick_f32(C.byref(d), tok.ptr, pos.ptr, None, 0, 1, None, 0, 0, None, ws.ptr, 64,
+                                          None) == -3
+    d = kx.make_gemv_desc(0, x.ptr, dw.ptr, dsc.ptr, y.ptr, 80, 4, GS, k0=4, k1=4)   # rows of 80: the generic kernel
+    assert L.kx_gemv_w8_classify_pick_f32(C.byref(d), tok.ptr, pos.ptr, None, 0, 1, None, 0, 0, None, ws.ptr,
+                                          ws.nbytes, None) == -2
+
+
 def test_streams_events_graph_replay():
     rng = np.random.default_rng(1)
     K, M = 256, 1024
