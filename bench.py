@@ -642,7 +642,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "gemv_w8_kernel (all W8 GEMV launches of a decode step, per rank)",
+                "kernel": "gemv_w8_kernel / gemv_w8_pick_kernel (all W8 GEMV launches of a decode step, per rank)",
                 "launches_timed": n_launch,
                 "algorithmic_bytes_per_launch": gemv_bytes / max(n_launch, 1),
                 "avg_launch_us": gemv_ms * 1e3 / max(n_launch, 1),

@@ -56,7 +56,8 @@ def main():
             "fetch_bytes_per_launch": 2.0 * 1024.0 * sf / nf if nf else None,
             "write_bytes_per_launch": 1024.0 * sw / nw if nw else None,
         }
-    gemv = {k: v for k, v in kernels.items() if "gemv_w8_kernel" in k}
+    # gemv_w8_pick_kernel: the classifier launch of the token loop (the GEMV that also ends the step)
+    gemv = {k: v for k, v in kernels.items() if "gemv_w8_kernel" in k or "gemv_w8_pick_kernel" in k}
     n = sum(v["launches_fetch_pass"] for v in gemv.values())
     fetch_total = sum(v["fetch_bytes_per_launch"] * v["launches_fetch_pass"] for v in gemv.values())
     nw = sum(v["launches_write_pass"] for v in gemv.values())

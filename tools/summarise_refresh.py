@@ -60,7 +60,7 @@ for sub, name in (("prof", "b_kernel_stats.csv"), ("prof_prefill", "p_kernel_sta
     for row in rows[:8]:
         out.append(f"  {row['Name'][:90]}: {row['Calls']} x {float(row['AverageNs']) / 1e3:.2f} us")
     for row in rows:
-        if "gemv_w8_kernel" in row["Name"]:
+        if "gemv_w8_kernel" in row["Name"] or "gemv_w8_pick_kernel" in row["Name"]:
             gemv_ns += float(row["TotalDurationNs"])
             gemv_calls += int(row["Calls"])
     if gemv_calls:
