@@ -201,7 +201,7 @@ __device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __res
   }
 }
 
-// ---- 4x4x1 form (head size 128, at most 4 query heads per kv head) --------------------------------
+// ---- 4x4x1 form (head sizes 128 and 64, at most 4 query heads per kv head and group) -------------
 // v_mfma_f32_16x16x4_f32 spends 16 head columns on kv_mul heads; with kv_mul = 4 three quarters of
 // its cycles are idle, and a 16-key tile costs its wave 64 such instructions on the critical path.
 // v_mfma_f32_4x4x1_16B_f32 is the same arithmetic (an fp32 fma chain per output) as 16 independent
@@ -211,22 +211,30 @@ __device__ __forceinline__ void attn_load_tile(AttnTile<HS>& T, const KVT* __res
 // quarters qd are summed across lanes afterwards.  Output: the probabilities of (key, head) go
 // through 64 floats of LDS per wave into "rows = heads", the V values are "columns = dims":
 // block b accumulates dims 4(l&31) + t for keys of parity l>>5, t = 0..3 in four accumulators.
+// With 64-wide heads a V row is 16 lanes wide: the lanes split into FOUR key phases l>>4 (key =
+// 4 step + phase) instead of two parities, and K / Q take 4 instead of 8 sixteen-dim steps.
+template <int HS>
 struct AttnTile4 {
-  f32x4 k[8];
-  f32x4 v[8];
+  static constexpr int NJ = HS / 16;       // 16-dim steps of K and Q per lane
+  static constexpr int LPR = HS / 4;       // lanes across a V row
+  static constexpr int PH = 64 / LPR;      // key phases of the second product (2 or 4)
+  static constexpr int NS = 16 / PH;       // its steps per tile (8 or 4)
+  f32x4 k[NJ];
+  f32x4 v[NS];
 };
 
-template <typename KVT>
-__device__ __forceinline__ void attn_load_tile4(AttnTile4& T, const KVT* __restrict__ kbase,
+template <int HS, typename KVT>
+__device__ __forceinline__ void attn_load_tile4(AttnTile4<HS>& T, const KVT* __restrict__ kbase,
                                                 const KVT* __restrict__ vbase, int key0, int last,
                                                 int kv_dim, int lane KX_BPARAM(9)) {
+  using TT = AttnTile4<HS>;
   const KVT* kr = kbase + (size_t)min(key0 + (lane & 15), last) * kv_dim + 4 * (lane >> 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) T.k[j] = load_kv4(KX_CKPN(AB_K, kr + 16 * j, 4 * sizeof(KVT)));
-  const int hi = lane >> 5, c4 = (lane & 31) * 4;
+  for (int j = 0; j < TT::NJ; ++j) T.k[j] = load_kv4(KX_CKPN(AB_K, kr + 16 * j, 4 * sizeof(KVT)));
+  const int ph = lane / TT::LPR, c4 = (lane % TT::LPR) * 4;
 #pragma unroll
-  for (int st = 0; st < 8; ++st)
-    T.v[st] = load_kv4(KX_CKPN(AB_V, vbase + (size_t)min(key0 + 2 * st + hi, last) * kv_dim + c4, 4 * sizeof(KVT)));
+  for (int st = 0; st < TT::NS; ++st)
+    T.v[st] = load_kv4(KX_CKPN(AB_V, vbase + (size_t)min(key0 + TT::PH * st + ph, last) * kv_dim + c4, 4 * sizeof(KVT)));
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -301,23 +309,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
   const int t_begin = cut.begin(split);
   const int t_end = t_begin + cut.count(split);
   if constexpr (M4 > 0) {
-    static_assert(M4 == 0 || HS == 128, "the 4x4x1 form is laid out for 128-wide heads");
+    static_assert(M4 == 0 || HS == 128 || HS == 64, "the 4x4x1 form is laid out for 128- and 64-wide heads");
+    using T4 = AttnTile4<HS>;
+    constexpr int NJ4 = T4::NJ, LPR4 = T4::LPR, PH4 = T4::PH, NS4 = T4::NS;
     // G groups of four query heads (kv_mul <= 4 G): every group repeats the two products on the
     // tile the wave holds in registers, with its own Q fragment, softmax state and accumulators
     constexpr int G = M4 > 0 ? M4 : 1;
-    const int qd = lane >> 4, kb = (lane >> 2) & 3, hd = lane & 3, hi = lane >> 5;
+    const int qd = lane >> 4, kb = (lane >> 2) & 3, hd = lane & 3, hi = lane / LPR4;  // hi: key phase
     // Q: lane (qd, *, head hd) holds Q[head][16j + 4qd + e]; requested ahead of the tile
-    f32x4 qf4[G][8];
+    f32x4 qf4[G][NJ4];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
       const float* qrow = q + ((size_t)kvh * kv_mul + min(4 * gi + hd, kv_mul - 1)) * HS + 4 * qd;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf4[gi][j] = *KX_CKP(AB_Q, reinterpret_cast<const f32x4*>(qrow + 16 * j));
+      for (int j = 0; j < NJ4; ++j) qf4[gi][j] = *KX_CKP(AB_Q, reinterpret_cast<const f32x4*>(qrow + 16 * j));
     }
 
     int t = t_begin + wave;
-    AttnTile4 cur;
-    if (t < t_end) attn_load_tile4<KVT>(cur, kbase, vbase, t << 4, last, kv_dim, lane KX_BFWD);
+    AttnTile4<HS> cur;
+    if (t < t_end) attn_load_tile4<HS, KVT>(cur, kbase, vbase, t << 4, last, kv_dim, lane KX_BFWD);
     // single-tile form: without the fences the scheduler sinks the tile loads into the product
     // loop and waits for them one at a time (the prefetching form schedules better without)
     if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
@@ -334,16 +344,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
 
     for (; t < t_end; t += kAttnWaves) {
       const int key0 = t << 4;
-      AttnTile4 nxt;
+      AttnTile4<HS> nxt;
       const bool more = t + kAttnWaves < t_end;
       if (PREFETCH && more)
-        attn_load_tile4<KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
+        attn_load_tile4<HS, KVT>(nxt, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
 #pragma unroll
       for (int gi = 0; gi < G; ++gi) {
         // ---- scores: rows = keys 4kb..4kb+3, columns = heads, this lane's quarter of the dims ----
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ4; ++j) {
           s0 = mfma4(cur.k[j].x, qf4[gi][j].x, s0);
           s1 = mfma4(cur.k[j].y, qf4[gi][j].y, s1);
           s0 = mfma4(cur.k[j].z, qf4[gi][j].z, s0);
@@ -371,12 +381,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] = fast_exp(sv[r] - m_sub);
         l_run[gi] = l_run[gi] * alpha + ((pv[0] + pv[1]) + (pv[2] + pv[3]));  // this lane's 4 keys
-        // P[key][head] -> LDS as [parity][head][step], key = 2 step + parity, so that a lane of
-        // the second product reads the 8 probabilities it needs as two 16-byte words
+        // P[key][head] -> LDS as [phase][head][step], key = PH4 step + phase, so that a lane of
+        // the second product reads the probabilities it needs as 16-byte words (two parities of 8
+        // steps for 128-wide heads, four phases of 4 steps for 64-wide ones)
         float* plg = pl + 64 * gi;
         if (qd == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) plg[((r & 1) * 4 + hd) * 8 + 2 * kb + (r >> 1)] = pv[r];
+          for (int r = 0; r < 4; ++r) {
+            const int key = 4 * kb + r;
+            plg[((key % PH4) * 4 + hd) * NS4 + key / PH4] = pv[r];
+          }
         }
         // the accumulators keep the head on the register axis: alpha of head r for every lane
         const float ah[4] = {dpp_mov<0x00>(alpha), dpp_mov<0x55>(alpha), dpp_mov<0xAA>(alpha),
@@ -385,12 +399,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
         for (int e = 0; e < 4; ++e) {
           o[gi][e].x *= ah[0]; o[gi][e].y *= ah[1]; o[gi][e].z *= ah[2]; o[gi][e].w *= ah[3];
         }
-        const f32x4 pa0 = *reinterpret_cast<const f32x4*>(plg + (hi * 4 + hd) * 8);
-        const f32x4 pa1 = *reinterpret_cast<const f32x4*>(plg + (hi * 4 + hd) * 8 + 4);
-        const float pa[8] = {pa0.x, pa0.y, pa0.z, pa0.w, pa1.x, pa1.y, pa1.z, pa1.w};
-        // ---- output: rows = heads, columns = dims 4(lane&31) + t, one key per step ----
+        float pa[NS4];
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
+        for (int w4 = 0; w4 < NS4 / 4; ++w4) {
+          const f32x4 pw = *reinterpret_cast<const f32x4*>(plg + (hi * 4 + hd) * NS4 + 4 * w4);
+          pa[4 * w4] = pw.x; pa[4 * w4 + 1] = pw.y; pa[4 * w4 + 2] = pw.z; pa[4 * w4 + 3] = pw.w;
+        }
+        // ---- output: rows = heads, columns = dims 4(lane % LPR4) + t, one key per step ----
+#pragma unroll
+        for (int st = 0; st < NS4; ++st) {
           o[gi][0] = mfma4(pa[st], cur.v[st].x, o[gi][0]);
           o[gi][1] = mfma4(pa[st], cur.v[st].y, o[gi][1]);
           o[gi][2] = mfma4(pa[st], cur.v[st].z, o[gi][2]);
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
       }
       if (more) {
         if (PREFETCH) cur = nxt;
-        else attn_load_tile4<KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
+        else attn_load_tile4<HS, KVT>(cur, kbase, vbase, (t + kAttnWaves) << 4, last, kv_dim, lane KX_BFWD);
       }
       if (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
     }
@@ -413,15 +430,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
         sm_m[wave][4 * gi + lane] = m_run[gi];
         sm_l[wave][4 * gi + lane] = lr;
       }
-      float oo[4][4];  // [head r][t], both key parities
+      float oo[4][4];  // [head r][t], all key phases
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         oo[0][e] = xor32_sum(o[gi][e].x);
         oo[1][e] = xor32_sum(o[gi][e].y);
         oo[2][e] = xor32_sum(o[gi][e].z);
         oo[3][e] = xor32_sum(o[gi][e].w);
+        if constexpr (PH4 == 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oo[r][e] = xor16_sum(oo[r][e]);
+        }
       }
-      if (lane < 32) {
+      if (lane < LPR4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (4 * gi + r < kv_mul)
@@ -779,7 +800,10 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
   // measured faster than the 16-column form: eight heads per kv head (Llama-3-70B) from 2048 keys on
   // (one kv head, 4368 keys: 13.8 vs 14.3 us; 1024 keys: 10.1 vs 9.8 us; seven heads -- Qwen2.5-7B,
   // the second group one head short -- 16.6 vs 16.1 us at 4368 keys).  KX_ATTN_M4X2=1 / =0 force it.
-  int m4 = head_size != 128 ? 0 : kv_mul <= 4 ? 1 : (kv_mul == 8 && pos >= 2047) ? 2 : 0;
+  // (64-wide heads: the one-group form only)
+  int m4 = head_size == 64 ? (kv_mul <= 4 ? 1 : 0)
+           : head_size != 128 ? 0 : kv_mul <= 4 ? 1 : (kv_mul == 8 && pos >= 2047) ? 2 : 0;
+  if (head_size == 64 && getenv("KX_ATTN_NO_M4_64")) m4 = 0;  // A/B runs and tests
   if (head_size == 128 && kv_mul > 4 && kv_mul <= 8)
     if (const char* e = getenv("KX_ATTN_M4X2")) m4 = e[0] == '1' ? 2 : 0;
   // Eight waves per workgroup, one workgroup per CU (4x4x1 forms): chosen where the four-wave form
@@ -837,7 +861,11 @@ static int mha_decode_launch(const float* query, const KVT* key_cache, const KVT
 #define KX_ATTN_LAUNCH(HS_, M4_) KX_ATTN_LAUNCH_NW(HS_, M4_, 4)
   switch (head_size) {
     case 32: KX_ATTN_LAUNCH(32, 0); break;
-    case 64: KX_ATTN_LAUNCH(64, 0); break;
+    case 64:
+      if (m4 == 1 && nw == 8) KX_ATTN_LAUNCH_NW(64, 1, 8);
+      else if (m4 == 1) KX_ATTN_LAUNCH(64, 1);
+      else KX_ATTN_LAUNCH(64, 0);
+      break;
     case 128:
       if (m4 == 1 && nw == 8) KX_ATTN_LAUNCH_NW(128, 1, 8);
       else if (m4 == 2 && nw == 8) KX_ATTN_LAUNCH_NW(128, 2, 8);

@@ -262,7 +262,9 @@ def test_mha_decode_two_head_groups_forced(H, KVH, hs, S, pos, monkeypatch):
 
 
 @pytest.mark.parametrize("H,KVH,hs,S,pos", [(32, 8, 128, 4700, 4367), (4, 1, 128, 300, 257), (6, 2, 128, 2100, 2047),
-                                            (3, 1, 128, 40, 15), (8, 1, 128, 9100, 9000), (16, 4, 128, 700, 640)])
+                                            (3, 1, 128, 40, 15), (8, 1, 128, 9100, 9000), (16, 4, 128, 700, 640),
+                                            (32, 8, 64, 4700, 4367), (8, 2, 64, 300, 257), (3, 1, 64, 40, 15),
+                                            (4, 4, 64, 2100, 2047)])
 def test_mha_decode_eight_wave_workgroups_forced(H, KVH, hs, S, pos, monkeypatch):
     # eight waves per workgroup (one workgroup per CU) is picked by itself only past the finest cut
     # of the four-wave form; forced here on short and long contexts, one and two head groups, and
