@@ -151,10 +151,13 @@ def run(N=40, seed=1):
         qkv_o = kxo.gemv_w8(kxo.rmsnorm(x2, g2, 1e-5), *mats["qkv"], GS) + bias
         qo, ko = kxo.rope(variant, ql, kl, hs, qkv_o[:ql].copy(), qkv_o[ql:ql + kl].copy(), pos, sin, cos)
         case = (dim, hid, H, KVH, hs, variant, pos)
-        kx.gemv_chain([d_wo, d_w13], ws, chain_id=int(rng.integers(0, 128)), pos=pos)
+        # every seam of a token needs its own chain_id (the tag of its granules): two different ones
+        id_a = int(rng.integers(0, 128))
+        kx.gemv_chain([d_wo, d_w13], ws, chain_id=id_a, pos=pos)
         report("chain Wo", case, np.abs(x.numpy() - x1), 3e-5 * max(1.0, np.abs(x1).max()) * np.ones_like(x1))
         report("chain W1|W3", case, np.abs(h.numpy() - hh), 3e-5 * max(1.0, np.abs(hh).max()) * np.ones_like(hh))
-        kx.gemv_chain([d_w2, d_qkv], ws, chain_id=int(rng.integers(0, 128)), pos=pos)
+        id_b = (id_a + 1 + int(rng.integers(0, 127))) % 128
+        kx.gemv_chain([d_w2, d_qkv], ws, chain_id=id_b, pos=pos)
         report("chain W2", case, np.abs(x.numpy() - x2), 3e-5 * max(1.0, np.abs(x2).max()) * np.ones_like(x2))
         report("chain q", case, np.abs(q.numpy() - qo), 3e-5 * max(1.0, np.abs(qo).max()) * np.ones_like(qo))
         report("chain k", case, np.abs(kc.numpy().reshape(S, kl)[pos] - ko), 3e-5 * max(1.0, np.abs(ko).max()) * np.ones_like(ko))
