@@ -280,7 +280,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_decode_kernel(
   __shared__ int sm_last;
   __shared__ __attribute__((aligned(16))) float sm_p[M4 ? kAttnWaves * 64 * M4 : 4];  // M4: P of one tile per wave and head group
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (readfirstlane: hipcc must know the wave index is uniform, or every test on it is a divergent
+  // branch whose two sides count each other's loads as pending)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int kvh = blockIdx.x, split = blockIdx.y;
   // The position may live in device memory so a captured launch can be replayed as it advances;

@@ -240,6 +240,13 @@ __device__ __forceinline__ void begin_rows(GemvRows<R, MODE == GEMV_GATE_UP>& S)
   }
 }
 
+// The position where an epilogue uses it: the empty statement keeps hipcc from working out
+// everything that depends on it ahead of the loop (which would wait for it there).
+__device__ __forceinline__ int late_pos(int pos) {
+  asm volatile("" : "+v"(pos));
+  return pos;
+}
+
 // Requests the epilogue operands of a row set ahead of its weights, so no dependent load is left
 // for the tail.  The values are only assigned here, never used: a use under the pointer test would
 // put a full wait inside the branch, one memory round trip per operand before the first weight is
@@ -262,8 +269,9 @@ __device__ __forceinline__ void request_epilogue(const GemvW8Args& a, int r0, in
       // such rows read entry 0, which nothing uses.
       const int in_head = row < a.k1 ? row % a.head_size : 0;
       const int tab = a.rope_variant == KX_ROPE_HALF_SPLIT ? in_head * 2 : in_head;
-      S.rope_s[r / 2] = *KX_CK(a, GB_SIN, a.sin_cache + ((size_t)pos * a.head_size + tab));
-      S.rope_c[r / 2] = *KX_CK(a, GB_COS, a.cos_cache + ((size_t)pos * a.head_size + tab));
+      const int p = late_pos(pos);
+      S.rope_s[r / 2] = *KX_CK(a, GB_SIN, a.sin_cache + ((size_t)p * a.head_size + tab));
+      S.rope_c[r / 2] = *KX_CK(a, GB_COS, a.cos_cache + ((size_t)p * a.head_size + tab));
     }
     S.bias[r] = b;
     S.residual[r] = res;
@@ -310,6 +318,7 @@ __device__ __forceinline__ void finish_rows(const GemvW8Args& a, int r0, int row
   }
   if (lane != 0) return;
   if constexpr (MODE == GEMV_QKV_ROPE) {
+    pos = late_pos(pos);
 #pragma unroll
     for (int r = 0; r < R; r += 2) {
       const int v = r0 + r;
@@ -353,7 +362,12 @@ __device__ __forceinline__ void gemv_w8_body(const GemvW8Args& a, float& best, i
   __shared__ float red[16];
   constexpr bool GU = MODE == GEMV_GATE_UP;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // readfirstlane: the wave index is uniform, and hipcc must know it -- with a lane-dependent
+  // index the "this wave has no rows" test below is a divergent branch, both sides of which are laid
+  // out one behind the other under exec masks; the loads of the idle side then count as pending on
+  // the working side and every request there is preceded by a full wait (x, then the bias, then the
+  // residual, then the first weights: round trip after round trip instead of all at once)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   const int out_rows = GU ? a.swiglu_half : a.K;
   const int row_begin = blockIdx.x * a.rows_per_block;
@@ -372,7 +386,19 @@ __device__ __forceinline__ void gemv_w8_body(const GemvW8Args& a, float& best, i
   }
   float rs = 1.0f;
   int pos = 0;
-  if constexpr (MODE == GEMV_QKV_ROPE) pos = a.pos_dev ? *KX_CK(a, GB_POS, a.pos_dev) : a.pos_val;
+  if constexpr (MODE == GEMV_QKV_ROPE) {
+    // The position is fetched with a VECTOR load (the lane-dependent zero hides the uniform
+    // address): as a scalar load hipcc waits for it together with the kernel arguments and works
+    // out the table and cache-row addresses ahead of the loop -- a memory round trip in front of
+    // the first weight request.  Behind x and ahead of the weights in the vector queue it costs
+    // nothing: it has long arrived when the epilogue asks for it (see late_pos).
+    pos = a.pos_val;
+    if (a.pos_dev) {
+      int lane_zero;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+      pos = *KX_CK(a, GB_POS, a.pos_dev + lane_zero);
+    }
+  }
 
   GemvBatch<R, U, GU> B;
   GemvRows<R, GU> S;
