@@ -783,7 +783,7 @@ __device__ __forceinline__ void gemm_f16_pipe_body(const GemmF16Args& a) {
 template <int S, bool ROPE>
 __global__ __launch_bounds__(256) void gemm_split_combine_kernel(const GemmF16Args a) {
   __shared__ __attribute__((aligned(16))) float lds[4][1024];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform, and hipcc knows
   const int unit = blockIdx.x * 4 + wv;              // (tile of the partial round, row block, wave position)
   const int r = unit >> 6, mi = (unit >> 3) & 7, wpos = unit & 7;
   const int wgid = a.full_tiles + r;
