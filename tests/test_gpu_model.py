@@ -1011,3 +1011,61 @@ def test_tensor_parallel_ranks_equal_single_rank(tp, shape):
     for m in ranks:
         m.close()
     host.loopback_destroy(group)
+
+
+# ---------------- the text front-end (demo/main.cpp:5-75) on the device -------------------------------
+def test_generate_front_end_matches_one_token_per_step(tmp_path):
+    # checkpoint file + tokenizer file -> words, as the demo: kx.generate opens the golden int8 export
+    # by its header, a SentencePiece model of the same vocabulary size (trained here; the reference
+    # ships none) tokenises, and the chunked graph-replayed loop must give the words of a host loop
+    # that asks for one token per step and tests each for the sentence end (demo/main.cpp:18-41).
+    import io
+    import os
+    import sentencepiece as spm
+    from kx import generate as gen
+    corpus = ["hello world this is a tiny corpus", "the quick brown fox jumps over the lazy dog",
+              "once upon a time there was a little model", "hello hello world"] * 20
+    w = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(corpus), model_writer=w, vocab_size=128,
+                                   model_type="bpe", bos_id=1, eos_id=2, unk_id=0, pad_id=-1, minloglevel=2)
+    tok_path = tmp_path / "tokenizer.model"
+    tok_path.write_bytes(w.getvalue())
+    ckpt = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_tiny_q8.bin")
+    tok = gen.open_tokenizer(str(tok_path), "llama2")
+    assert tok.vocab_size() == 128
+
+    class EndsAt:  # a tokenizer whose sentence end is a token the stream is known to reach
+        def __init__(self, inner, end):
+            self.inner, self.end = inner, end
+        def encode(self, s): return self.inner.encode(s)
+        def decode(self, ids): return self.inner.decode(ids)
+        def is_sentence_ending(self, t): return int(t) == self.end
+
+    sentence = "once upon a time there was"
+    tokens = tok.encode(sentence)
+    n = len(tokens)
+    # the one-token-per-step loop: same prompt pass, then single eager steps read back one by one
+    ref = gen.open_model(ckpt, "llama2", seq_len=32)
+    ref.prefill(np.asarray(tokens, np.int32))
+    stream = [ref.state()[0]]
+    for _ in range(32 - n):
+        ref.decode(1, use_graph=False)
+        stream.append(ref.state()[0])
+    ref.close()
+    m = gen.open_model(ckpt, "llama2", seq_len=32)
+    for total, chunk in ((n - 1, 16), (n + 5, 4), (1000, 16), (1000, 5)):
+        steps, words = gen.generate(m, tok, sentence, total, chunk=chunk)
+        sampled = min(max(total - (n - 1), 0), 32 - n + 1)
+        want = tokens[1:] + [t for t in stream[:sampled]]
+        if tok.is_sentence_ending(2) and 2 in stream[:sampled]:
+            want = tokens[1:] + stream[:stream.index(2)]
+        assert words == want and steps == len(want), (total, chunk)
+    # a sentence end in the middle of a chunk: the words stop in front of it
+    end = stream[6]
+    first = stream.index(end)
+    steps, words = gen.generate(m, EndsAt(tok, end), sentence, 1000, chunk=4)
+    assert words == tokens[1:] + stream[:first] and steps == n - 1 + first
+    out = io.StringIO()
+    gen.generate(m, tok, sentence, n + 3, need_output=True, out=out)
+    assert out.getvalue().startswith(sentence[:4])
+    m.close()
