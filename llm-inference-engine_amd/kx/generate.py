@@ -100,7 +100,11 @@ def generate(model, tokenizer, sentence, total_steps, need_output=False, chunk=1
         raise ValueError("The tokens is empty.")
     n = len(tokens)
     words = []
-    if total_steps <= n - 1:  # the loop would end inside the prompt
+    if getattr(getattr(model, "cfg", None), "group_size", 1) == 0:
+        # fp32 weights (the demo's own default, a legacy export): no fused token loop -- the
+        # reference-structured step through op::Layer and the kernel registry, one position at a time
+        pos, words = _generate_stepwise(model, tokenizer, tokens, total_steps)
+    elif total_steps <= n - 1:  # the loop would end inside the prompt
         words = tokens[1:total_steps + 1]
         pos = max(total_steps, 0)
     else:
@@ -135,6 +139,25 @@ def generate(model, tokenizer, sentence, total_steps, need_output=False, chunk=1
     return min(pos, total_steps), words
 
 
+def _generate_stepwise(model, tokenizer, tokens, total_steps):
+    """demo/main.cpp:18-41 as written: forward at every position, the sampler's pick from the last
+    prompt position on (argmax_sampler.cpp:6-8 on the host here)."""
+    n, pos, nxt, words = len(tokens), 0, -1, []
+    total_steps = min(total_steps, model.cfg.seq_len)
+    while pos < total_steps:
+        if pos < n - 1:
+            model.forward_layers(tokens[pos], pos)
+            nxt = tokens[pos + 1]
+        else:
+            logits = model.forward_layers(tokens[pos] if pos == n - 1 else nxt, pos)
+            nxt = int(np.argmax(logits))
+            if tokenizer.is_sentence_ending(nxt):
+                break
+        words.append(nxt)
+        pos += 1
+    return pos, words
+
+
 def read_header(blob):
     """dim, hidden_dim, layers, heads, kv heads, vocabulary (negative: classifier of its own), seq_len
     (model.cpp:52-122); quant files carry the group size behind them (tools/export_llama.py:134-150)."""
@@ -166,14 +189,13 @@ def main(argv=None):
     ap.add_argument("checkpoint")
     ap.add_argument("tokenizer")
     ap.add_argument("--family", choices=sorted(FAMILIES), default="llama2")
-    ap.add_argument("--fp32", action="store_true", help="legacy fp32 export instead of the int8 one")
+    ap.add_argument("--fp32", action="store_true",
+                    help="legacy fp32 export (one reference-structured step per position) instead of the int8 one")
     ap.add_argument("--prompt", default="hello")
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--seq-len", type=int, default=None)
     a = ap.parse_args(argv)
-    if a.fp32:
-        sys.exit("the fused token loop runs the int8 export; fp32 files go through forward_layers (tests)")
-    model = open_model(a.checkpoint, a.family, quant=True, seq_len=a.seq_len)
+    model = open_model(a.checkpoint, a.family, quant=not a.fp32, seq_len=a.seq_len)
     tok = open_tokenizer(a.tokenizer, a.family)
     print("Generating...", flush=True)
     t0 = time.perf_counter()

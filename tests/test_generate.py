@@ -147,3 +147,29 @@ def test_export_header_fields(golden_bytes):
     # model.cpp:52-122: seven int32, then the group size in a quant file
     dim, hidden, layers, heads, kv_heads, vocab, seq = gen.read_header(golden_bytes("g4_tiny_q8.bin"))
     assert (dim, hidden, layers, heads, kv_heads, abs(vocab)) == (128, 256, 2, 4, 2, 128) and seq > 0
+
+
+def test_generate_stepwise_for_fp32_models_is_the_demo_loop(spe):
+    # a model without the fused token loop (fp32 weights: group_size 0) is stepped one position at a
+    # time through forward_layers, exactly the demo's loop
+    class Fp32Rule(RuleModel):
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.cfg.group_size = 0
+            self.calls = []
+
+        def forward_layers(self, token, pos):
+            self.calls.append((int(token), pos))
+            logits = np.zeros(self.vocab, np.float32)
+            logits[self.rule(int(token), pos)] = 1.0
+            return logits
+
+    tokens = spe.encode("once upon a time")
+    n = len(tokens)
+    for end_at in (None, 3, 9):
+        for total in (0, 2, n - 1, n, n + 6, 30):
+            m = Fp32Rule(96, spe.sp.eos_id(), end_at)
+            m.cfg = type("Cfg", (), dict(seq_len=64, group_size=0))()
+            want = demo_loop(lambda t, p, pr: -1 if pr else m.rule(t, p), tokens, total, spe.is_sentence_ending)
+            assert gen.generate(m, spe, "once upon a time", total) == want, (end_at, total)
+            assert [p for _, p in m.calls] == list(range(len(m.calls)))  # every position once, in order

@@ -1069,3 +1069,28 @@ def test_generate_front_end_matches_one_token_per_step(tmp_path):
     gen.generate(m, tok, sentence, n + 3, need_output=True, out=out)
     assert out.getvalue().startswith(sentence[:4])
     m.close()
+
+
+def test_generate_front_end_reproduces_the_golden_streams(golden):
+    # the fixtures' prompt ids in, the reference implementation's greedy streams out: the fp32 export
+    # one reference-structured step per position (the demo's default model kind), the int8 export
+    # through prefill + chunked graph-replayed decode
+    import os
+    from kx import generate as gen
+
+    class Fixed:  # stands in for the tokenizer: the sentence IS the fixture's prompt
+        def __init__(self, ids):
+            self.ids = ids
+        def encode(self, s): return list(self.ids)
+        def decode(self, ids): return " ".join(str(i) for i in ids)
+        def is_sentence_ending(self, t): return False
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, quant in (("g3_tiny_fp32", False), ("g4_tiny_q8", True)):
+        g = golden(name + ".npz")
+        toks, greedy = g["tokens"].tolist(), g["greedy"].tolist()
+        m = gen.open_model(os.path.join(here, name + ".bin"), "llama2", quant=quant, seq_len=32)
+        total = len(toks) - 1 + len(greedy)
+        steps, words = gen.generate(m, Fixed(toks), "the fixture's prompt", total, chunk=5)
+        assert words == toks[1:] + greedy and steps == total, name
+        m.close()
