@@ -1069,6 +1069,13 @@ def test_generate_front_end_matches_one_token_per_step(tmp_path):
     gen.generate(m, tok, sentence, n + 3, need_output=True, out=out)
     assert out.getvalue().startswith(sentence[:4])
     m.close()
+    # and the command line (demo/main.cpp:50-75): checkpoint path, tokenizer path -> text and steps/s
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = gen.main([ckpt, str(tok_path), "--family", "llama2", "--prompt", sentence, "--steps", "12",
+                       "--seq-len", "32"])
+    assert rc == 0 and buf.getvalue().startswith("Generating...") and "steps/s:" in buf.getvalue()
 
 
 def test_generate_front_end_reproduces_the_golden_streams(golden):
